@@ -1,0 +1,55 @@
+// Shared device/host helpers for the gfx950 kernels of libfdgs.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fdgs.h"
+
+#define FDGS_WAVE 64
+
+#define FDGS_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return FDGS_ELAUNCH; \
+    } while (0)
+
+// Rasterizer constants (the published tile-rasterizer algorithm).
+#define FDGS_NEAR_Z 0.2f
+#define FDGS_COV_DILATION 0.3f
+#define FDGS_ALPHA_MAX 0.99f
+#define FDGS_ALPHA_MIN (1.0f / 255.0f)
+#define FDGS_T_STOP 0.0001f
+
+// Spherical-harmonics constants, src/utils/sh_utils.py:26-43 of the reference.
+#define SH_C0 0.28209479177387814f
+#define SH_C1 0.4886025119029199f
+#define SH_C2_0 1.0925484305920792f
+#define SH_C2_1 -1.0925484305920792f
+#define SH_C2_2 0.31539156525252005f
+#define SH_C2_3 -1.0925484305920792f
+#define SH_C2_4 0.5462742152960396f
+#define SH_C3_0 -0.5900435899266435f
+#define SH_C3_1 2.890611442640554f
+#define SH_C3_2 -0.4570457994644658f
+#define SH_C3_3 0.3731763325901154f
+#define SH_C3_4 -0.4570457994644658f
+#define SH_C3_5 1.445305721320277f
+#define SH_C3_6 -0.5900435899266435f
+
+static inline int fdgs_tiles_x(int w) { return (w + FDGS_TILE - 1) / FDGS_TILE; }
+static inline int fdgs_tiles_y(int h) { return (h + FDGS_TILE - 1) / FDGS_TILE; }
+
+// Tile rectangle touched by a splat of integer radius r centred at (px,py).
+// Clamping happens in float before the conversion so that the result is defined
+// for any finite input and identical to clamp((int)f, 0, grid) where that is defined.
+__device__ __forceinline__ void fdgs_tile_rect(float px, float py, float r, int gx, int gy,
+                                               int& x0, int& y0, int& x1, int& y1) {
+#pragma clang fp contract(off)
+    float fx0 = (px - r) / (float)FDGS_TILE;
+    float fy0 = (py - r) / (float)FDGS_TILE;
+    float fx1 = (px + r + (float)(FDGS_TILE - 1)) / (float)FDGS_TILE;
+    float fy1 = (py + r + (float)(FDGS_TILE - 1)) / (float)FDGS_TILE;
+    fx0 = (fx0 != fx0) ? 0.0f : fminf(fmaxf(fx0, 0.0f), (float)gx);
+    fy0 = (fy0 != fy0) ? 0.0f : fminf(fmaxf(fy0, 0.0f), (float)gy);
+    fx1 = (fx1 != fx1) ? 0.0f : fminf(fmaxf(fx1, 0.0f), (float)gx);
+    fy1 = (fy1 != fy1) ? 0.0f : fminf(fmaxf(fy1, 0.0f), (float)gy);
+    x0 = (int)fx0; y0 = (int)fy0; x1 = (int)fx1; y1 = (int)fy1;
+}

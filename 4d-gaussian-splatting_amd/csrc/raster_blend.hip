@@ -1,0 +1,241 @@
+// Rasterizer stage 6 (front-to-back alpha blending) and stage 7 (its backward).
+//
+// gfx950 mapping: one 256-thread workgroup per 16x16 tile, but each of its four
+// wavefronts owns one 8x8 pixel quadrant and walks the tile's depth-sorted list
+// on its own, with no workgroup barrier.  A batch of 64 list entries is loaded
+// one per lane; every lane tests whether its entry's 1/255-alpha ellipse can
+// reach the wave's quadrant, a 64-bit ballot collects the survivors and the wave
+// iterates over the set bits in list order, broadcasting the survivor's record
+// from its lane with v_readlane (scalar registers, no LDS).  Entries that cannot
+// reach the quadrant cost nothing; a quadrant stops as soon as its 64 pixels are
+// saturated.
+#include "fdgs_common.h"
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// Can the splat contribute alpha >= 1/255 anywhere in [rx0,rx1]x[ry0,ry1]?
+// alpha = o*exp(power) >= 1/255  <=>  A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o).
+// The test uses the axis-aligned box of that ellipse, enlarged by a safety
+// margin that covers float rounding in the per-pixel evaluation.
+__device__ __forceinline__ bool splat_reaches(float gx, float gy, float A, float B, float C, float o, float rx0,
+                                              float ry0, float rx1, float ry1) {
+    const float tau = __logf(255.0f * o);
+    if (!(tau >= 0.0f)) return false;             // also rejects o <= 0 and NaN
+    const float s = 2.0f * tau * 1.001f + 0.001f;
+    const float det = A * C - B * B;
+    if (!(det > 0.0f)) return true;               // degenerate conic: never skip
+    const float inv = s / det;
+    const float hx = sqrtf(inv * C) + 0.01f;
+    const float hy = sqrtf(inv * A) + 0.01f;
+    return (gx + hx >= rx0) && (gx - hx <= rx1) && (gy + hy >= ry0) && (gy - hy <= ry1);
+}
+
+__global__ void __launch_bounds__(256)
+blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
+    const int tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qx0 = tx * FDGS_TILE + (wave & 1) * 8, qy0 = ty * FDGS_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const int W = a.image_width, H = a.image_height;
+    const bool inside = pxi < W && pyi < H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+
+    const uint32_t r_begin = a.ranges[2 * tile], r_end = a.ranges[2 * tile + 1];
+    const float4* __restrict__ geom4 = reinterpret_cast<const float4*>(a.geom);
+
+    float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (uint32_t base = r_begin; base < r_end; base += 64) {
+        if (__ballot(!done) == 0ull) break;
+        const uint32_t e = base + lane;
+        const bool valid = e < r_end;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+        if (valid) {
+            const uint32_t id = a.point_list[e];
+            g0 = geom4[3 * (size_t)id + 0];
+            g1 = geom4[3 * (size_t)id + 1];
+            g2 = geom4[3 * (size_t)id + 2];
+        }
+        const bool hit = valid && splat_reaches(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, rx0, ry0, rx1, ry1);
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const float ex = bcast(g0.x, j), ey = bcast(g0.y, j);
+            const float A = bcast(g0.z, j), B = bcast(g0.w, j), C = bcast(g1.x, j), o = bcast(g1.y, j);
+            const float dx = ex - pxf, dy = ey - pyf;
+            const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
+            const float alpha = fminf(FDGS_ALPHA_MAX, o * __expf(power));
+            if (!done && power <= 0.0f && alpha >= FDGS_ALPHA_MIN) {
+                const float test_T = T * (1.0f - alpha);
+                if (test_T < FDGS_T_STOP) {
+                    done = true;
+                } else {
+                    const float w = alpha * T;
+                    Cr += bcast(g1.z, j) * w;
+                    Cg += bcast(g1.w, j) * w;
+                    Cb += bcast(g2.x, j) * w;
+                    D += bcast(g2.y, j) * w;
+                    T = test_T;
+                    last = (base - r_begin) + (uint32_t)j + 1u;
+                }
+            }
+            if (__ballot(!done) == 0ull) { mask = 0ull; }
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)pyi * W + pxi, plane = (size_t)W * H;
+        a.out_color[pix] = Cr + T * a.bg[0];
+        a.out_color[plane + pix] = Cg + T * a.bg[1];
+        a.out_color[2 * plane + pix] = Cb + T * a.bg[2];
+        a.out_depth[pix] = D;
+        a.final_T[pix] = T;
+        a.n_contrib[pix] = last;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Backward
+// ---------------------------------------------------------------------------
+// Wave-wide sum; the total is returned from lane 63 (as a wave-uniform value).
+// Row-level Hillis-Steele steps with row_shr DPP, then the two cross-row
+// broadcasts (row_bcast:15, row_bcast:31) of the GCN/CDNA DPP set.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(t);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return bcast(v, 63);
+}
+
+__global__ void __launch_bounds__(256)
+blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
+    const int tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qx0 = tx * FDGS_TILE + (wave & 1) * 8, qy0 = ty * FDGS_TILE + (wave >> 1) * 8;
+    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const int W = a.image_width, H = a.image_height;
+    const bool inside = pxi < W && pyi < H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+
+    const uint32_t r_begin = a.ranges[2 * tile], r_end = a.ranges[2 * tile + 1];
+    if (r_begin >= r_end) return;
+    const float4* __restrict__ geom4 = reinterpret_cast<const float4*>(a.geom);
+
+    float T_final = 1.0f, dLr = 0.f, dLg = 0.f, dLb = 0.f;
+    int ncon = 0;
+    if (inside) {
+        const size_t pix = (size_t)pyi * W + pxi, plane = (size_t)W * H;
+        T_final = a.final_T[pix];
+        ncon = (int)a.n_contrib[pix];
+        dLr = a.dL_dcolor[pix];
+        dLg = a.dL_dcolor[plane + pix];
+        dLb = a.dL_dcolor[2 * plane + pix];
+    }
+    const float bg_dot = a.bg[0] * dLr + a.bg[1] * dLg + a.bg[2] * dLb;
+    float T = T_final;
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
+
+    int wave_last = ncon;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d));
+    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+
+    for (int hi = wave_last; hi > 0; hi -= 64) {
+        const int pos = hi - 1 - lane;        // 0-based position in the tile list, back to front
+        const bool valid = pos >= 0;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+        uint32_t id = 0;
+        if (valid) {
+            id = a.point_list[r_begin + (uint32_t)pos];
+            g0 = geom4[3 * (size_t)id + 0];
+            g1 = geom4[3 * (size_t)id + 1];
+            g2 = geom4[3 * (size_t)id + 2];
+        }
+        const bool hit = valid && splat_reaches(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, rx0, ry0, rx1, ry1);
+        unsigned long long mask = __ballot(hit);
+        while (mask) {
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            const int p = hi - 1 - j;
+            const float ex = bcast(g0.x, j), ey = bcast(g0.y, j);
+            const float A = bcast(g0.z, j), B = bcast(g0.w, j), C = bcast(g1.x, j), o = bcast(g1.y, j);
+            const float dx = ex - pxf, dy = ey - pyf;
+            const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(FDGS_ALPHA_MAX, o * G);
+            const bool contrib = (p < ncon) && power <= 0.0f && alpha >= FDGS_ALPHA_MIN;
+            if (__ballot(contrib) == 0ull) continue;
+
+            float v_mx = 0.f, v_my = 0.f, v_A = 0.f, v_B = 0.f, v_C = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
+            if (contrib) {
+                const float cr = bcast(g1.z, j), cg = bcast(g1.w, j), cb = bcast(g2.x, j);
+                const float one_m = 1.0f - alpha;
+                T = T / one_m;
+                const float w = alpha * T;
+                acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r;
+                acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g;
+                acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b;
+                last_r = cr; last_g = cg; last_b = cb;
+                float dL_dalpha = (cr - acc_r) * dLr + (cg - acc_g) * dLg + (cb - acc_b) * dLb;
+                v_r = w * dLr; v_g = w * dLg; v_b = w * dLb;
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / one_m) * bg_dot;
+                const float dL_dG = o * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                v_mx = dL_dG * (-gdx * A - gdy * B);
+                v_my = dL_dG * (-gdy * C - gdx * B);
+                v_A = -0.5f * gdx * dx * dL_dG;
+                v_B = -gdx * dy * dL_dG;
+                v_C = -0.5f * gdy * dy * dL_dG;
+                v_o = G * dL_dalpha;
+            }
+            const float s0 = wave_sum(v_mx), s1 = wave_sum(v_my), s2 = wave_sum(v_A), s3 = wave_sum(v_B);
+            const float s4 = wave_sum(v_C), s5 = wave_sum(v_o), s6 = wave_sum(v_r), s7 = wave_sum(v_g);
+            const float s8 = wave_sum(v_b);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
+            if (lane < 9) {
+                float v = s0;
+                v = lane == 1 ? s1 : v; v = lane == 2 ? s2 : v; v = lane == 3 ? s3 : v; v = lane == 4 ? s4 : v;
+                v = lane == 5 ? s5 : v; v = lane == 6 ? s6 : v; v = lane == 7 ? s7 : v; v = lane == 8 ? s8 : v;
+                atomicAdd(a.dL_dgeom + (size_t)gid * FDGS_GEOM_FLOATS + lane, v);
+            }
+        }
+    }
+}
+
+extern "C" int fdgs_raster_blend_fwd(const fdgs_blend_fwd_args* a, void* stream) {
+    if (!a || a->image_width <= 0 || a->image_height <= 0) return FDGS_EINVAL;
+    if (!a->ranges || !a->geom || !a->bg || !a->out_color || !a->out_depth || !a->final_T || !a->n_contrib)
+        return FDGS_EINVAL;   // point_list may be NULL when every range is empty
+    const int gx = fdgs_tiles_x(a->image_width), gy = fdgs_tiles_y(a->image_height);
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(256), 0, (hipStream_t)stream, *a, gx);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_raster_blend_bwd(const fdgs_blend_bwd_args* a, void* stream) {
+    if (!a || a->image_width <= 0 || a->image_height <= 0) return FDGS_EINVAL;
+    if (!a->ranges || !a->geom || !a->bg || !a->final_T || !a->n_contrib || !a->dL_dcolor || !a->dL_dgeom)
+        return FDGS_EINVAL;
+    const int gx = fdgs_tiles_x(a->image_width), gy = fdgs_tiles_y(a->image_height);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(gx * gy), dim3(256), 0, (hipStream_t)stream, *a, gx);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}

@@ -1,0 +1,368 @@
+// Rasterizer stages 1-3 and 5: per-Gaussian preprocess, inclusive scan of
+// tiles_touched, duplicateWithKeys, identifyTileRanges.
+//
+// This translation unit is compiled with -ffp-contract=off: every float
+// expression that feeds an integer decision (radius, tile rectangle, depth bits
+// of the sort key) is a sequence of single IEEE operations in a fixed order, so
+// that the integer stages are reproducible bit for bit by any IEEE
+// implementation that evaluates the same sequence.
+#include "fdgs_common.h"
+
+#pragma clang fp contract(off)
+
+// ---------------------------------------------------------------------------
+// Stage 1: one thread per Gaussian.  HBM-bound: reads 59 floats, writes the
+// 48-byte record + radius + tiles_touched.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.num_points) return;
+    const int W = a.image_width, H = a.image_height;
+    const int gx = (W + FDGS_TILE - 1) / FDGS_TILE, gy = (H + FDGS_TILE - 1) / FDGS_TILE;
+    const float* __restrict__ V = a.viewmatrix;
+    const float* __restrict__ P = a.projmatrix;
+
+    float4* grec = reinterpret_cast<float4*>(a.geom) + 3 * (size_t)i;
+    const float x = a.means3D[3 * i + 0], y = a.means3D[3 * i + 1], z = a.means3D[3 * i + 2];
+
+    const float pvx = V[0] * x + V[4] * y + V[8] * z + V[12];
+    const float pvy = V[1] * x + V[5] * y + V[9] * z + V[13];
+    const float pvz = V[2] * x + V[6] * y + V[10] * z + V[14];
+    bool visible = pvz > FDGS_NEAR_Z;
+
+    int radius = 0;
+    uint32_t touched = 0;
+    float px = 0.f, py = 0.f, conA = 0.f, conB = 0.f, conC = 0.f;
+    float cr = 0.f, cg = 0.f, cb = 0.f;
+    int clampmask = 0;
+    if (visible) {
+        const float phx = P[0] * x + P[4] * y + P[8] * z + P[12];
+        const float phy = P[1] * x + P[5] * y + P[9] * z + P[13];
+        const float phw = P[3] * x + P[7] * y + P[11] * z + P[15];
+        const float p_w = 1.0f / (phw + 1e-7f);
+        const float ppx = phx * p_w, ppy = phy * p_w;
+
+        // 3-D covariance Sigma = (R S)(R S)^T, R as the reference's build_rotation
+        // (src/utils/general_utils.py:108-121) for a normalised (w,x,y,z).
+        const float mod = a.scale_modifier;
+        const float sx = mod * a.scales[3 * i + 0], sy = mod * a.scales[3 * i + 1], sz = mod * a.scales[3 * i + 2];
+        const float qr = a.rotations[4 * i + 0], qx = a.rotations[4 * i + 1];
+        const float qy = a.rotations[4 * i + 2], qz = a.rotations[4 * i + 3];
+        const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz);
+        const float R01 = 2.0f * (qx * qy - qr * qz);
+        const float R02 = 2.0f * (qx * qz + qr * qy);
+        const float R10 = 2.0f * (qx * qy + qr * qz);
+        const float R11 = 1.0f - 2.0f * (qx * qx + qz * qz);
+        const float R12 = 2.0f * (qy * qz - qr * qx);
+        const float R20 = 2.0f * (qx * qz - qr * qy);
+        const float R21 = 2.0f * (qy * qz + qr * qx);
+        const float R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+        const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+        const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+        const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+        const float c00 = M00 * M00 + M01 * M01 + M02 * M02;
+        const float c01 = M00 * M10 + M01 * M11 + M02 * M12;
+        const float c02 = M00 * M20 + M01 * M21 + M02 * M22;
+        const float c11 = M10 * M10 + M11 * M11 + M12 * M12;
+        const float c12 = M10 * M20 + M11 * M21 + M12 * M22;
+        const float c22 = M20 * M20 + M21 * M21 + M22 * M22;
+
+        // EWA projection
+        const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
+        const float fx = (float)W / (2.0f * a.tanfovx), fy = (float)H / (2.0f * a.tanfovy);
+        const float tz = pvz;
+        const float tx = fminf(limx, fmaxf(-limx, pvx / tz)) * tz;
+        const float ty = fminf(limy, fmaxf(-limy, pvy / tz)) * tz;
+        const float J00 = fx / tz;
+        const float J02 = -(fx * tx) / (tz * tz);
+        const float J11 = fy / tz;
+        const float J12 = -(fy * ty) / (tz * tz);
+        const float T00 = J00 * V[0] + J02 * V[2];
+        const float T01 = J00 * V[4] + J02 * V[6];
+        const float T02 = J00 * V[8] + J02 * V[10];
+        const float T10 = J11 * V[1] + J12 * V[2];
+        const float T11 = J11 * V[5] + J12 * V[6];
+        const float T12 = J11 * V[9] + J12 * V[10];
+        const float U00 = T00 * c00 + T01 * c01 + T02 * c02;
+        const float U01 = T00 * c01 + T01 * c11 + T02 * c12;
+        const float U02 = T00 * c02 + T01 * c12 + T02 * c22;
+        const float U10 = T10 * c00 + T11 * c01 + T12 * c02;
+        const float U11 = T10 * c01 + T11 * c11 + T12 * c12;
+        const float U12 = T10 * c02 + T11 * c12 + T12 * c22;
+        const float ca = U00 * T00 + U01 * T01 + U02 * T02 + FDGS_COV_DILATION;
+        const float cb2 = U00 * T10 + U01 * T11 + U02 * T12;
+        const float cc = U10 * T10 + U11 * T11 + U12 * T12 + FDGS_COV_DILATION;
+        const float det = ca * cc - cb2 * cb2;
+        visible = (det != 0.0f);
+        if (visible) {
+            const float det_inv = 1.0f / det;
+            conA = cc * det_inv;
+            conB = -cb2 * det_inv;
+            conC = ca * det_inv;
+            const float mid = 0.5f * (ca + cc);
+            const float disc = sqrtf(fmaxf(mid * mid - det, 0.1f));
+            const float lam = fmaxf(mid + disc, mid - disc);
+            float rad_f = ceilf(3.0f * sqrtf(lam));
+            rad_f = (rad_f != rad_f) ? 0.0f : fminf(rad_f, 16777216.0f);
+            px = ((ppx + 1.0f) * (float)W - 1.0f) * 0.5f;
+            py = ((ppy + 1.0f) * (float)H - 1.0f) * 0.5f;
+            int x0, y0, x1, y1;
+            fdgs_tile_rect(px, py, rad_f, gx, gy, x0, y0, x1, y1);
+            const int area = (x1 - x0) * (y1 - y0);
+            visible = area > 0;
+            if (visible) {
+                radius = (int)rad_f;
+                touched = (uint32_t)area;
+            }
+        }
+        if (visible) {
+            // colour from SH, basis and signs as src/utils/sh_utils.py:57-100
+            const float ddx = x - a.campos[0], ddy = y - a.campos[1], ddz = z - a.campos[2];
+            const float nrm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            const float ux = ddx / nrm, uy = ddy / nrm, uz = ddz / nrm;
+            const float* __restrict__ sh = a.shs + (size_t)i * 48;
+            float res[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) res[c] = SH_C0 * sh[c];
+            if (a.sh_degree > 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    res[c] = res[c] - (SH_C1 * uy) * sh[3 + c] + (SH_C1 * uz) * sh[6 + c] - (SH_C1 * ux) * sh[9 + c];
+                if (a.sh_degree > 1) {
+                    const float xx = ux * ux, yy = uy * uy, zz = uz * uz;
+                    const float xy = ux * uy, yz = uy * uz, xz = ux * uz;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        res[c] = res[c] + (SH_C2_0 * xy) * sh[12 + c] + (SH_C2_1 * yz) * sh[15 + c] +
+                                 (SH_C2_2 * (2.0f * zz - xx - yy)) * sh[18 + c] + (SH_C2_3 * xz) * sh[21 + c] +
+                                 (SH_C2_4 * (xx - yy)) * sh[24 + c];
+                    if (a.sh_degree > 2) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            res[c] = res[c] + ((SH_C3_0 * uy) * (3.0f * xx - yy)) * sh[27 + c] +
+                                     ((SH_C3_1 * xy) * uz) * sh[30 + c] +
+                                     ((SH_C3_2 * uy) * (4.0f * zz - xx - yy)) * sh[33 + c] +
+                                     ((SH_C3_3 * uz) * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * sh[36 + c] +
+                                     ((SH_C3_4 * ux) * (4.0f * zz - xx - yy)) * sh[39 + c] +
+                                     ((SH_C3_5 * uz) * (xx - yy)) * sh[42 + c] +
+                                     ((SH_C3_6 * ux) * (xx - 3.0f * yy)) * sh[45 + c];
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                res[c] = res[c] + 0.5f;
+                if (res[c] < 0.0f) { clampmask |= (1 << c); res[c] = 0.0f; }
+            }
+            cr = res[0]; cg = res[1]; cb = res[2];
+        }
+    }
+    const float op = visible ? a.opacities[i] : 0.0f;
+    grec[0] = make_float4(px, py, conA, conB);
+    grec[1] = make_float4(conC, op, cr, cg);
+    grec[2] = make_float4(cb, pvz, __int_as_float(radius), __int_as_float(clampmask));
+    a.radii[i] = radius;
+    a.tiles_touched[i] = touched;
+}
+
+// ---------------------------------------------------------------------------
+// Stage 2: inclusive scan of uint32 counts.  Three small launches:
+// per-chunk sums, a single-block scan of the chunk sums, per-chunk scan + base.
+// ---------------------------------------------------------------------------
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < FDGS_WAVE; d <<= 1) {
+        uint32_t n = __shfl_up(v, d);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (256 threads); returns the
+// exclusive prefix, *total gets the block total.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total, uint32_t* lds4) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == 63) lds4[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t s = lds4[w];
+        if (w < wave) base += s;
+    }
+    *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_chunk_sums_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ chunk_sums, int n) {
+    __shared__ uint32_t lds4[4];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) s += in[base + k];
+    uint32_t total;
+    block_excl_scan_256(s, &total, lds4);
+    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_chunk_bases_kernel(uint32_t* __restrict__ chunk_sums, int n_chunks) {
+    __shared__ uint32_t lds4[4];
+    uint32_t carry = 0;
+    for (int start = 0; start < n_chunks; start += SCAN_THREADS) {
+        const int idx = start + threadIdx.x;
+        uint32_t v = idx < n_chunks ? chunk_sums[idx] : 0u;
+        uint32_t total;
+        uint32_t excl = block_excl_scan_256(v, &total, lds4);
+        if (idx < n_chunks) chunk_sums[idx] = carry + excl;   // exclusive base of the chunk
+        carry += total;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ chunk_bases,
+                  uint32_t* __restrict__ out, int n) {
+    __shared__ uint32_t lds4[4];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t run = chunk_bases[blockIdx.x] + block_excl_scan_256(s, &total, lds4);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        run += v[k];
+        if (base + k < n) out[base + k] = run;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Stage 3: duplicateWithKeys.  One thread per Gaussian writes one (key,value)
+// per touched tile, tiles row-major.  key = (tile_id << 32) | bits(depth).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+duplicate_with_keys_kernel(int n, const float* __restrict__ geom, const uint32_t* __restrict__ offsets,
+                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, int gy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 g2 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 2];
+    const int radius = __float_as_int(g2.z);
+    if (radius <= 0) return;
+    const float4 g0 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 0];
+    uint32_t off = (i == 0) ? 0u : offsets[i - 1];
+    int x0, y0, x1, y1;
+    fdgs_tile_rect(g0.x, g0.y, (float)radius, gx, gy, x0, y0, x1, y1);
+    const uint64_t dbits = (uint64_t)__float_as_uint(g2.y);
+    for (int ty = y0; ty < y1; ++ty)
+        for (int tx = x0; tx < x1; ++tx) {
+            keys[off] = ((uint64_t)(uint32_t)(ty * gx + tx) << 32) | dbits;
+            vals[off] = (uint32_t)i;
+            ++off;
+        }
+}
+
+// ---------------------------------------------------------------------------
+// Stage 5: identifyTileRanges over the sorted keys.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+identify_tile_ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, uint32_t* __restrict__ ranges) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= R) return;
+    const uint32_t tile = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) ranges[2 * tile] = 0u;
+    else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (prev != tile) {
+            ranges[2 * prev + 1] = (uint32_t)idx;
+            ranges[2 * tile] = (uint32_t)idx;
+        }
+    }
+    if (idx == R - 1) ranges[2 * tile + 1] = (uint32_t)R;
+}
+
+// ---------------------------------------------------------------------------
+// Host entry points
+// ---------------------------------------------------------------------------
+extern "C" size_t fdgs_raster_scan_workspace_bytes(int32_t num_points) {
+    if (num_points < 0) return 0;
+    size_t chunks = ((size_t)num_points + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    return (chunks + 1) * sizeof(uint32_t);
+}
+
+extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, void* stream) {
+    if (!a || a->num_points < 0 || a->image_width <= 0 || a->image_height <= 0) return FDGS_EINVAL;
+    if (a->sh_degree < 0 || a->sh_degree > 3) return FDGS_EINVAL;
+    const int n = a->num_points;
+    if (n == 0) return FDGS_OK;
+    if (!a->viewmatrix || !a->projmatrix || !a->campos || !a->means3D || !a->scales || !a->rotations ||
+        !a->opacities || !a->shs || !a->geom || !a->radii || !a->tiles_touched || !a->point_offsets ||
+        !a->scan_workspace)
+        return FDGS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *a);
+    FDGS_CHECK_LAUNCH();
+    const int chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
+                       a->scan_workspace, n);
+    FDGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scan_chunk_bases_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, a->scan_workspace, chunks);
+    FDGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
+                       a->scan_workspace, a->point_offsets, n);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}
+
+// sort lives in radix_sort.hip
+int fdgs_radix_sort_passes(int end_bit);
+int fdgs_radix_sort_pingpong(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int64_t n,
+                             int end_bit, void* workspace, size_t workspace_bytes, hipStream_t s);
+
+extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
+    if (!a || a->num_points < 0 || a->num_rendered < 0 || a->image_width <= 0 || a->image_height <= 0)
+        return FDGS_EINVAL;
+    if (a->num_rendered > 0x7fffffffLL) return FDGS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = fdgs_tiles_x(a->image_width), gy = fdgs_tiles_y(a->image_height);
+    const int tiles = gx * gy;
+    if (!a->ranges) return FDGS_EINVAL;
+    if (hipMemsetAsync(a->ranges, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s) != hipSuccess) return FDGS_ELAUNCH;
+    const int64_t R = a->num_rendered;
+    if (R == 0 || a->num_points == 0) return FDGS_OK;
+    if (!a->geom || !a->point_offsets || !a->keys_unsorted || !a->vals_unsorted || !a->keys_sorted ||
+        !a->vals_sorted || !a->sort_workspace)
+        return FDGS_EINVAL;
+    if (a->sort_workspace_bytes < fdgs_raster_sort_workspace_bytes(R)) return FDGS_EWORKSPACE;
+    int tile_bits = 0;
+    while ((1 << tile_bits) < tiles) ++tile_bits;   // keys are < tiles << 32
+    const int end_bit = 32 + tile_bits;
+    // The sort ping-pongs between the two buffer pairs; start in the pair that
+    // makes the last pass land in keys_sorted / vals_sorted.
+    const bool odd = fdgs_radix_sort_passes(end_bit) & 1;
+    uint64_t* ka = odd ? a->keys_unsorted : a->keys_sorted;
+    uint32_t* va = odd ? a->vals_unsorted : a->vals_sorted;
+    uint64_t* kb = odd ? a->keys_sorted : a->keys_unsorted;
+    uint32_t* vb = odd ? a->vals_sorted : a->vals_unsorted;
+    hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((a->num_points + 255) / 256), dim3(256), 0, s, a->num_points,
+                       a->geom, a->point_offsets, ka, va, gx, gy);
+    FDGS_CHECK_LAUNCH();
+    int rc = fdgs_radix_sort_pingpong(ka, va, kb, vb, R, end_bit, a->sort_workspace, a->sort_workspace_bytes, s);
+    if (rc != FDGS_OK) return rc;
+    hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R,
+                       a->keys_sorted, a->ranges);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}

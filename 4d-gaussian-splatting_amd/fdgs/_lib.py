@@ -1,0 +1,146 @@
+"""ctypes binding of libfdgs.so (the C ABI declared in include/fdgs.h).
+
+The library is the only compute path: there is no CPU or PyTorch fallback.  If
+the shared object is missing or a symbol cannot be resolved, importing this
+module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdgs.so")
+
+MAX_LEVELS = 4
+GEOM_FLOATS = 12
+TILE = 16
+
+c_f = C.c_float
+c_i32 = C.c_int32
+c_i64 = C.c_int64
+c_p = C.c_void_p
+c_sz = C.c_size_t
+
+
+class PreprocessFwdArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("sh_degree", c_i32), ("image_width", c_i32), ("image_height", c_i32),
+                ("tanfovx", c_f), ("tanfovy", c_f), ("scale_modifier", c_f),
+                ("viewmatrix", c_p), ("projmatrix", c_p), ("campos", c_p),
+                ("means3D", c_p), ("scales", c_p), ("rotations", c_p), ("opacities", c_p), ("shs", c_p),
+                ("geom", c_p), ("radii", c_p), ("tiles_touched", c_p), ("point_offsets", c_p),
+                ("scan_workspace", c_p)]
+
+
+class BinSortArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("image_width", c_i32), ("image_height", c_i32), ("num_rendered", c_i64),
+                ("geom", c_p), ("point_offsets", c_p),
+                ("keys_unsorted", c_p), ("vals_unsorted", c_p), ("keys_sorted", c_p), ("vals_sorted", c_p),
+                ("ranges", c_p), ("sort_workspace", c_p), ("sort_workspace_bytes", c_sz)]
+
+
+class BlendFwdArgs(C.Structure):
+    _fields_ = [("image_width", c_i32), ("image_height", c_i32),
+                ("ranges", c_p), ("point_list", c_p), ("geom", c_p), ("bg", c_p),
+                ("out_color", c_p), ("out_depth", c_p), ("final_T", c_p), ("n_contrib", c_p)]
+
+
+class BlendBwdArgs(C.Structure):
+    _fields_ = [("image_width", c_i32), ("image_height", c_i32),
+                ("ranges", c_p), ("point_list", c_p), ("geom", c_p), ("bg", c_p),
+                ("final_T", c_p), ("n_contrib", c_p), ("dL_dcolor", c_p), ("dL_dgeom", c_p)]
+
+
+class PreprocessBwdArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("sh_degree", c_i32), ("image_width", c_i32), ("image_height", c_i32),
+                ("tanfovx", c_f), ("tanfovy", c_f), ("scale_modifier", c_f),
+                ("viewmatrix", c_p), ("projmatrix", c_p), ("campos", c_p),
+                ("means3D", c_p), ("scales", c_p), ("rotations", c_p), ("shs", c_p),
+                ("geom", c_p), ("dL_dgeom", c_p),
+                ("dL_dmeans3D", c_p), ("dL_dmeans2D", c_p), ("dL_dscales", c_p), ("dL_drotations", c_p),
+                ("dL_dopacities", c_p), ("dL_dshs", c_p)]
+
+
+class DeformParams(C.Structure):
+    _fields_ = [("num_levels", c_i32), ("res", (c_i32 * 4) * MAX_LEVELS), ("aabb", c_p),
+                ("planes", (c_p * 6) * MAX_LEVELS), ("w0", c_p), ("b0", c_p),
+                ("w1", c_p * 5), ("b1", c_p * 5), ("w2", c_p * 5), ("b2", c_p * 5)]
+
+
+class DeformParamGrads(C.Structure):
+    _fields_ = [("planes", (c_p * 6) * MAX_LEVELS), ("w0", c_p), ("b0", c_p),
+                ("w1", c_p * 5), ("b1", c_p * 5), ("w2", c_p * 5), ("b2", c_p * 5)]
+
+
+class DeformFwdArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("p", DeformParams),
+                ("xyz", c_p), ("scales", c_p), ("rotations", c_p), ("opacity", c_p), ("shs", c_p),
+                ("time", c_p), ("time_scalar", c_f),
+                ("out_xyz", c_p), ("out_scales", c_p), ("out_rotations", c_p), ("out_opacity", c_p),
+                ("out_shs", c_p), ("save_hidden", c_p)]
+
+
+class DeformBwdArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("p", DeformParams),
+                ("xyz", c_p), ("time", c_p), ("time_scalar", c_f), ("hidden", c_p),
+                ("g_xyz", c_p), ("g_scales", c_p), ("g_rotations", c_p), ("g_opacity", c_p), ("g_shs", c_p),
+                ("d_xyz", c_p), ("dp", DeformParamGrads), ("workspace", c_p), ("workspace_bytes", c_sz)]
+
+
+# every symbol include/fdgs.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "fdgs_strerror": (C.c_char_p, [C.c_int]),
+    "fdgs_abi_version": (C.c_int, []),
+    "fdgs_raster_scan_workspace_bytes": (c_sz, [c_i32]),
+    "fdgs_raster_preprocess_fwd": (C.c_int, [C.POINTER(PreprocessFwdArgs), c_p]),
+    "fdgs_raster_sort_workspace_bytes": (c_sz, [c_i64]),
+    "fdgs_raster_bin_sort": (C.c_int, [C.POINTER(BinSortArgs), c_p]),
+    "fdgs_raster_blend_fwd": (C.c_int, [C.POINTER(BlendFwdArgs), c_p]),
+    "fdgs_raster_blend_bwd": (C.c_int, [C.POINTER(BlendBwdArgs), c_p]),
+    "fdgs_raster_preprocess_bwd": (C.c_int, [C.POINTER(PreprocessBwdArgs), c_p]),
+    "fdgs_deform_fwd": (C.c_int, [C.POINTER(DeformFwdArgs), c_p]),
+    "fdgs_deform_bwd_workspace_bytes": (c_sz, [c_i32]),
+    "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
+}
+
+ABI_VERSION = 1
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                          f"(hipcc --offload-arch=gfx950); there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fdgs_abi_version() != ABI_VERSION:
+        raise ImportError(f"libfdgs.so ABI {lib.fdgs_abi_version()} != binding ABI {ABI_VERSION}")
+    return lib
+
+
+lib = _load()
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise RuntimeError(f"{what}: {lib.fdgs_strerror(status).decode()} ({status})")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "libfdgs needs contiguous tensors"
+    return t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("libfdgs kernels run on the GPU only; got a tensor on " + str(t.device))
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,231 @@
+/*
+ * fdgs.h — C ABI of the MI355X (gfx950) 4D-Gaussian-splatting hot path.
+ *
+ * One shared library, libfdgs.so.  Plain pointers and sizes only: every pointer
+ * below is a DEVICE pointer unless its comment says "host".  The caller owns
+ * every buffer (inputs, outputs, workspaces); the library allocates nothing,
+ * keeps no state between calls, starts no threads and no streams.  Every entry
+ * point enqueues its kernels on the HIP stream passed in (`stream` is a
+ * hipStream_t, spelled void* so that this header needs no HIP include) and
+ * returns without synchronising.  Return value: FDGS_OK (0) or a negative
+ * fdgs_status; fdgs_strerror() names it.  No C++ exception crosses the ABI.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference repository):
+ *   - the rasterizer entry points together are the body of
+ *     diff_gaussian_rasterization.GaussianRasterizer.forward / backward, the
+ *     third-party extension called at src/gaussian_renderer/__init__.py:104-113
+ *     (settings built at :38-51) and differentiated by loss.backward() at
+ *     src/runner/fdgs_trainer.py:140;
+ *   - fdgs_deform_fwd / fdgs_deform_bwd are DeformationFields.forward
+ *     (src/model/deformation.py:218-243, i.e. HexPlaneField.forward at
+ *     src/model/hexplane.py:198-204 + DeformationNet.forward_dynamic at
+ *     src/model/deformation.py:111-163) and its autograd backward.
+ *
+ * Layout invariants: row-major contiguous float32; quaternions (w,x,y,z)
+ * (src/utils/general_utils.py:108-111); SH coefficients [N,16,3], coefficient
+ * major / channel minor (src/model/gaussian_model.py:86-89); 4x4 matrices in the
+ * row-vector form of src/scene/camera.py:48-52 (p_view = [x y z 1] @ M);
+ * images planar [3,H,W].
+ */
+#ifndef FDGS_H
+#define FDGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    FDGS_OK = 0,
+    FDGS_EINVAL = -1,      /* null pointer, negative size, unsupported configuration */
+    FDGS_ELAUNCH = -2,     /* a kernel launch was rejected by the runtime            */
+    FDGS_EWORKSPACE = -3   /* workspace smaller than fdgs_*_workspace_bytes() asks   */
+} fdgs_status;
+
+const char* fdgs_strerror(int status);
+/* ABI version of the loaded library (bumped on any struct change). */
+int fdgs_abi_version(void);
+
+#define FDGS_TILE 16                 /* tile edge in pixels                         */
+#define FDGS_GEOM_FLOATS 12          /* floats per Gaussian in the packed record    */
+
+/* Packed per-Gaussian record written by preprocess and gathered by the blend
+ * kernels (48 bytes, one or two cache lines per gather):
+ *   [0] x_pix  [1] y_pix  [2] conic A  [3] conic B
+ *   [4] conic C [5] opacity [6] r [7] g
+ *   [8] b      [9] view depth [10] radius (int32 bits) [11] SH clamp mask (int32 bits, bit c = channel c clamped)
+ */
+
+/* ---- rasterizer forward, stage 1+2: per-Gaussian preprocess + inclusive scan --------------- */
+typedef struct {
+    int32_t num_points;
+    int32_t sh_degree;               /* active degree 0..3                          */
+    int32_t image_width, image_height;
+    float tanfovx, tanfovy, scale_modifier;
+    const float* viewmatrix;         /* [16]                                        */
+    const float* projmatrix;         /* [16]                                        */
+    const float* campos;             /* [3]                                         */
+    const float* means3D;            /* [N,3]                                       */
+    const float* scales;             /* [N,3] activated (exp already applied)       */
+    const float* rotations;          /* [N,4] normalised                            */
+    const float* opacities;          /* [N]   activated (sigmoid already applied)   */
+    const float* shs;                /* [N,16,3]                                    */
+    /* outputs */
+    float* geom;                     /* [N,12] packed record (see above)            */
+    int32_t* radii;                  /* [N]   0 = not visible                       */
+    uint32_t* tiles_touched;         /* [N]                                         */
+    uint32_t* point_offsets;         /* [N]   inclusive scan of tiles_touched; R = point_offsets[N-1] */
+    uint32_t* scan_workspace;        /* fdgs_raster_scan_workspace_bytes(N) bytes   */
+} fdgs_preprocess_fwd_args;
+
+size_t fdgs_raster_scan_workspace_bytes(int32_t num_points);
+int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, void* stream);
+
+/* ---- rasterizer forward, stages 3-5: duplicateWithKeys, radix sort, identifyTileRanges ----- */
+typedef struct {
+    int32_t num_points;
+    int32_t image_width, image_height;
+    int64_t num_rendered;            /* R, read back by the caller from point_offsets[N-1] */
+    const float* geom;               /* [N,12]                                      */
+    const uint32_t* point_offsets;   /* [N]                                         */
+    /* outputs */
+    uint64_t* keys_unsorted;         /* [R] (tile_id << 32) | bits(depth)           */
+    uint32_t* vals_unsorted;         /* [R] Gaussian index                          */
+    uint64_t* keys_sorted;           /* [R]                                         */
+    uint32_t* vals_sorted;           /* [R] the per-tile, depth-ordered point list  */
+    uint32_t* ranges;                /* [tiles,2] (first, last+1); (0,0) when empty */
+    void* sort_workspace;            /* fdgs_raster_sort_workspace_bytes(R) bytes   */
+    size_t sort_workspace_bytes;
+} fdgs_binsort_args;
+
+size_t fdgs_raster_sort_workspace_bytes(int64_t num_rendered);
+int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream);
+
+/* ---- rasterizer forward, stage 6: front-to-back alpha blending ------------------------------ */
+typedef struct {
+    int32_t image_width, image_height;
+    const uint32_t* ranges;          /* [tiles,2]                                   */
+    const uint32_t* point_list;      /* [R] = vals_sorted                           */
+    const float* geom;               /* [N,12]                                      */
+    const float* bg;                 /* [3]                                         */
+    /* outputs */
+    float* out_color;                /* [3,H,W]                                     */
+    float* out_depth;                /* [1,H,W]  sum depth_i alpha_i T_i            */
+    float* final_T;                  /* [H,W]                                       */
+    uint32_t* n_contrib;             /* [H,W] 1-based list position of the last contributor */
+} fdgs_blend_fwd_args;
+
+int fdgs_raster_blend_fwd(const fdgs_blend_fwd_args* a, void* stream);
+
+/* ---- rasterizer backward, stage 7: back-to-front blending gradients ------------------------- */
+typedef struct {
+    int32_t image_width, image_height;
+    const uint32_t* ranges;
+    const uint32_t* point_list;
+    const float* geom;
+    const float* bg;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const float* dL_dcolor;          /* [3,H,W]                                     */
+    /* output: per-Gaussian accumulators, MUST be zero on entry.  [N,12]:
+     *   [0] dL/dx_pix [1] dL/dy_pix [2] dL/dA [3] dL/dB [4] dL/dC [5] dL/dopacity
+     *   [6..8] dL/drgb  [9..11] unused                                            */
+    float* dL_dgeom;
+} fdgs_blend_bwd_args;
+
+int fdgs_raster_blend_bwd(const fdgs_blend_bwd_args* a, void* stream);
+
+/* ---- rasterizer backward, stage 8: per-Gaussian chain rule back to the inputs --------------- */
+typedef struct {
+    int32_t num_points;
+    int32_t sh_degree;
+    int32_t image_width, image_height;
+    float tanfovx, tanfovy, scale_modifier;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* campos;
+    const float* means3D;
+    const float* scales;
+    const float* rotations;
+    const float* shs;
+    const float* geom;               /* [N,12] from the forward (radius, clamp mask) */
+    const float* dL_dgeom;           /* [N,12] from fdgs_raster_blend_bwd            */
+    /* outputs (fully written, no need to zero) */
+    float* dL_dmeans3D;              /* [N,3]                                       */
+    float* dL_dmeans2D;              /* [N,3]  (0.5*W*dL/dx_pix, 0.5*H*dL/dy_pix, 0) */
+    float* dL_dscales;               /* [N,3]  w.r.t. the activated scales          */
+    float* dL_drotations;            /* [N,4]  w.r.t. the normalised quaternion     */
+    float* dL_dopacities;            /* [N]                                         */
+    float* dL_dshs;                  /* [N,16,3]                                    */
+} fdgs_preprocess_bwd_args;
+
+int fdgs_raster_preprocess_bwd(const fdgs_preprocess_bwd_args* a, void* stream);
+
+/* ---- HexPlane deformation field ------------------------------------------------------------- */
+#define FDGS_DEFORM_MAX_LEVELS 4
+#define FDGS_DEFORM_WIDTH 128        /* hidden width W of every Linear (configs/train/dynerf.yaml:86) */
+#define FDGS_DEFORM_FEAT 16          /* channels per plane (dynerf.yaml:98)         */
+#define FDGS_DEFORM_OUT 59           /* 3 + 3 + 4 + 1 + 48 head outputs             */
+
+typedef struct {
+    int32_t num_levels;                              /* len(multires)               */
+    int32_t res[FDGS_DEFORM_MAX_LEVELS][4];          /* per level: x,y,z,t resolution */
+    const float* aabb;                               /* [2,3] row0 = xyz_max, row1 = xyz_min (hexplane.py:134-136,174-180) */
+    /* planes[level][ci], ci over (0,1),(0,2),(0,3),(1,2),(1,3),(2,3): [16, res[b], res[a]] */
+    const float* planes[FDGS_DEFORM_MAX_LEVELS][6];
+    const float* w0; const float* b0;                /* feature_out.0: [128, 16*levels], [128] */
+    /* heads in the order pos, scales, rotations, opacity, shs */
+    const float* w1[5]; const float* b1[5];          /* <head>_deform.1: [128,128],[128] */
+    const float* w2[5]; const float* b2[5];          /* <head>_deform.3: [k,128],[k], k = 3,3,4,1,48 */
+} fdgs_deform_params;
+
+typedef struct {                                     /* gradient buffers, same shapes; accumulated INTO (+=) */
+    float* planes[FDGS_DEFORM_MAX_LEVELS][6];
+    float* w0; float* b0;
+    float* w1[5]; float* b1[5];
+    float* w2[5]; float* b2[5];
+} fdgs_deform_param_grads;
+
+typedef struct {
+    int32_t num_points;
+    fdgs_deform_params p;
+    const float* xyz;                /* [N,3]                                       */
+    const float* scales;             /* [N,3]  raw (log)                            */
+    const float* rotations;          /* [N,4]  raw                                  */
+    const float* opacity;            /* [N,1]  raw (logit)                          */
+    const float* shs;                /* [N,16,3]                                    */
+    const float* time;               /* [N,1] per-point time, or NULL to use time_scalar */
+    float time_scalar;
+    /* outputs */
+    float* out_xyz; float* out_scales; float* out_rotations; float* out_opacity; float* out_shs;
+    /* saved for backward (may be NULL when no gradient is needed):
+     *   hidden [N,128] pre-activation output of feature_out                       */
+    float* save_hidden;
+} fdgs_deform_fwd_args;
+
+int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream);
+
+typedef struct {
+    int32_t num_points;
+    fdgs_deform_params p;
+    const float* xyz;
+    const float* time; float time_scalar;
+    const float* hidden;             /* [N,128] saved by the forward                */
+    const float* g_xyz; const float* g_scales; const float* g_rotations; const float* g_opacity; const float* g_shs; /* output cotangents */
+    /* outputs */
+    float* d_xyz;                    /* [N,3] = g_xyz + d(features)/d(xyz) path     */
+    fdgs_deform_param_grads dp;      /* accumulated into; caller zeroes             */
+    void* workspace;                 /* fdgs_deform_bwd_workspace_bytes(N) bytes    */
+    size_t workspace_bytes;
+} fdgs_deform_bwd_args;
+
+size_t fdgs_deform_bwd_workspace_bytes(int32_t num_points);
+int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDGS_H */
