@@ -77,7 +77,7 @@ class DeformFwdArgs(C.Structure):
                 ("xyz", c_p), ("scales", c_p), ("rotations", c_p), ("opacity", c_p), ("shs", c_p),
                 ("time", c_p), ("time_scalar", c_f),
                 ("out_xyz", c_p), ("out_scales", c_p), ("out_rotations", c_p), ("out_opacity", c_p),
-                ("out_shs", c_p), ("save_hidden", c_p)]
+                ("out_shs", c_p), ("save_hidden", c_p), ("workspace", c_p), ("workspace_bytes", c_sz)]
 
 
 class DeformBwdArgs(C.Structure):
@@ -98,8 +98,9 @@ SYMBOLS = {
     "fdgs_raster_blend_fwd": (C.c_int, [C.POINTER(BlendFwdArgs), c_p]),
     "fdgs_raster_blend_bwd": (C.c_int, [C.POINTER(BlendBwdArgs), c_p]),
     "fdgs_raster_preprocess_bwd": (C.c_int, [C.POINTER(PreprocessBwdArgs), c_p]),
+    "fdgs_deform_fwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams)]),
     "fdgs_deform_fwd": (C.c_int, [C.POINTER(DeformFwdArgs), c_p]),
-    "fdgs_deform_bwd_workspace_bytes": (c_sz, [c_i32]),
+    "fdgs_deform_bwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 

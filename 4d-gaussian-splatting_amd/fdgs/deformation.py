@@ -1,0 +1,233 @@
+"""Drop-in for the reference's `DeformationFields` (src/model/deformation.py:180-250).
+
+Same constructor (`DeformationFields(kwargs)` with the keys of
+configs/train/dynerf.yaml:85-111), same `forward(point, scales, rotations,
+opacity, shs, time)` -> 5-tuple, same `state_dict()` keys and shapes (so a
+reference-trained `deformation.pth` loads), same helpers the trainer and the
+scene use: `get_mlp_parameters()` / `get_grid_parameters()` (split on "grid" in
+the parameter name, deformation.py:165-177), `deformation_net.set_aabb`,
+`deformation_net.grid.grids`, `get_aabb`.
+
+The module only holds parameters; forward and backward run in libfdgs.so
+(fdgs_deform_fwd / fdgs_deform_bwd).  The positional encodings of
+deformation.py:235-237 are not evaluated: every consumer slices them back to
+their identity part (deformation.py:86,130,137,147), so outputs and gradients are
+unchanged.
+"""
+import ctypes as C
+import itertools
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import lib, ptr, check, stream_ptr
+
+PLANE_AXES = list(itertools.combinations(range(4), 2))
+HEADS = ("pos", "scales", "rotations", "opacity", "shs")
+HEAD_DIMS = (3, 3, 4, 1, 48)
+
+
+class HexPlaneField(nn.Module):
+    """Parameter container with the layout of src/model/hexplane.py:128-180."""
+
+    def __init__(self, bounds, planeconfig, multires):
+        super().__init__()
+        aabb = torch.tensor([[bounds, bounds, bounds], [-bounds, -bounds, -bounds]], dtype=torch.float32)
+        self.aabb = nn.Parameter(aabb, requires_grad=False)
+        self.grid_config = [planeconfig]
+        self.multiscale_res_multipliers = list(multires)
+        self.concat_features = True
+        self.grids = nn.ModuleList()
+        self.feat_dim = 0
+        self.resolutions = []
+        out_dim = planeconfig["output_coordinate_dim"]
+        for m in self.multiscale_res_multipliers:
+            reso = [r * m for r in planeconfig["resolution"][:3]] + list(planeconfig["resolution"][3:])
+            self.resolutions.append(reso)
+            gp = nn.ParameterList()
+            for (a, b) in PLANE_AXES:
+                g = nn.Parameter(torch.empty(1, out_dim, reso[b], reso[a]))
+                if b == 3:                       # planes with a time axis start at one (hexplane.py:80-81)
+                    nn.init.ones_(g)
+                else:
+                    nn.init.uniform_(g, a=0.1, b=0.5)
+                gp.append(g)
+            self.grids.append(gp)
+            self.feat_dim += out_dim
+
+    @property
+    def get_aabb(self):
+        return self.aabb[0], self.aabb[1]
+
+    def set_aabb(self, xyz_max, xyz_min):
+        """Row 0 = xyz_max, row 1 = xyz_min (src/model/hexplane.py:174-180)."""
+        dev = self.aabb.device
+        aabb = torch.tensor([list(map(float, xyz_max)), list(map(float, xyz_min))], dtype=torch.float32, device=dev)
+        self.aabb = nn.Parameter(aabb, requires_grad=False)
+
+
+def _head(width, out_dim):
+    return nn.Sequential(nn.ReLU(), nn.Linear(width, width), nn.ReLU(), nn.Linear(width, out_dim))
+
+
+class DeformationNet(nn.Module):
+    def __init__(self, W, grid_pe, bounds, kplanes_config, multires):
+        super().__init__()
+        self.W = W
+        self.grid_pe = grid_pe
+        self.grid = HexPlaneField(bounds, kplanes_config, multires)
+        self.feature_out = nn.Sequential(nn.Linear(self.grid.feat_dim, W))     # defor_depth - 1 == -1 extra layers
+        self.pos_deform = _head(W, 3)
+        self.scales_deform = _head(W, 3)
+        self.rotations_deform = _head(W, 4)
+        self.opacity_deform = _head(W, 1)
+        self.shs_deform = _head(W, 48)
+
+    @property
+    def get_aabb(self):
+        return self.grid.get_aabb
+
+    def set_aabb(self, xyz_max, xyz_min):
+        self.grid.set_aabb(xyz_max, xyz_min)
+
+    def get_mlp_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" not in n]
+
+    def get_grid_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" in n]
+
+
+def _fill_params(net, grads=None):
+    """fdgs_deform_params (or the gradient twin) from the module's tensors."""
+    grid = net.grid
+    src = (lambda t: t) if grads is None else (lambda t: grads[id(t)])
+    P = _lib.DeformParams() if grads is None else _lib.DeformParamGrads()
+    if grads is None:
+        P.num_levels = len(grid.grids)
+        for l, reso in enumerate(grid.resolutions):
+            for k in range(4):
+                P.res[l][k] = int(reso[k])
+        P.aabb = ptr(grid.aabb.detach())
+    for l, gp in enumerate(grid.grids):
+        for ci in range(6):
+            P.planes[l][ci] = ptr(src(gp[ci]))
+    P.w0 = ptr(src(net.feature_out[0].weight))
+    P.b0 = ptr(src(net.feature_out[0].bias))
+    for h, name in enumerate(HEADS):
+        seq = getattr(net, name + "_deform")
+        P.w1[h] = ptr(src(seq[1].weight)); P.b1[h] = ptr(src(seq[1].bias))
+        P.w2[h] = ptr(src(seq[3].weight)); P.b2[h] = ptr(src(seq[3].bias))
+    return P
+
+
+def _trainable(net):
+    ts = []
+    for gp in net.grid.grids:
+        ts += list(gp)
+    ts += [net.feature_out[0].weight, net.feature_out[0].bias]
+    for name in HEADS:
+        seq = getattr(net, name + "_deform")
+        ts += [seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias]
+    return ts
+
+
+class _DeformFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, xyz, scales, rotations, opacity, shs, time, *params):
+        _lib.require_gpu(xyz, scales, rotations, opacity, shs, time, *params)
+        N = xyz.shape[0]
+        dev = xyz.device
+        c = lambda t: t.detach().to(torch.float32).contiguous()
+        xyz_c, sc_c, ro_c, op_c, sh_c = c(xyz), c(scales), c(rotations), c(opacity), c(shs)
+        time_c = c(time).reshape(-1) if time is not None else None
+        if time_c is not None and time_c.numel() != N:
+            raise ValueError("time must have one entry per point")
+        outs = [torch.empty_like(t) for t in (xyz_c, sc_c, ro_c, op_c, sh_c)]
+        need_grad = any(ctx.needs_input_grad)
+        hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if need_grad else None
+        P = _fill_params(net)
+        ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P))
+        ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+        a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), 0.0,
+                               ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(outs[4]), ptr(hidden),
+                               ptr(ws), ws_bytes)
+        check(lib.fdgs_deform_fwd(C.byref(a), stream_ptr()), "fdgs_deform_fwd")
+        ctx.net = net
+        ctx.save_for_backward(xyz_c, time_c, hidden)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_sc, g_ro, g_op, g_sh):
+        net = ctx.net
+        xyz_c, time_c, hidden = ctx.saved_tensors
+        N = xyz_c.shape[0]
+        dev = xyz_c.device
+        c = lambda t, like: (torch.zeros_like(like) if t is None else t.to(torch.float32).contiguous())
+        g_xyz = c(g_xyz, xyz_c)
+        g_sc = c(g_sc, torch.empty(N, 3, device=dev)); g_ro = c(g_ro, torch.empty(N, 4, device=dev))
+        g_op = c(g_op, torch.empty(N, 1, device=dev)); g_sh = c(g_sh, torch.empty(N, 16, 3, device=dev))
+        params = _trainable(net)
+        grads = {id(p): torch.zeros_like(p, memory_format=torch.contiguous_format) for p in params}
+        P = _fill_params(net)
+        G = _fill_params(net, grads)
+        d_xyz = torch.empty_like(xyz_c)
+        ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
+        ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), 0.0, ptr(hidden), ptr(g_xyz), ptr(g_sc), ptr(g_ro),
+                               ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
+        check(lib.fdgs_deform_bwd(C.byref(a), stream_ptr()), "fdgs_deform_bwd")
+        pg = tuple(grads[id(p)] for p in params)
+        # net, xyz, scales, rotations, opacity, shs, time, *params
+        return (None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + pg
+
+
+class DeformationFields(nn.Module):
+    def __init__(self, kwargs):
+        super().__init__()
+        self.net_width = kwargs["net_width"]
+        self.timebase_pe = kwargs["timebase_pe"]
+        self.defor_depth = kwargs["defor_depth"]
+        self.posebase_pe = kwargs["posebase_pe"]
+        self.scale_rotation_pe = kwargs["scale_rotation_pe"]
+        self.opacity_pe = kwargs["opacity_pe"]
+        self.grid_pe = kwargs["grid_pe"]
+        self.no_grid = kwargs["no_grid"]
+        self.bounds = kwargs["bounds"]
+        self.kplanes_config = kwargs["kplanes_config"]
+        self.multires = kwargs["multires"]
+        self.empty_voxel = kwargs["empty_voxel"]
+        self.static_mlp = kwargs["static_mlp"]
+        if (self.net_width != 128 or self.defor_depth > 1 or self.grid_pe != 0 or self.empty_voxel or
+                self.static_mlp or len(self.multires) != 2 or self.kplanes_config["output_coordinate_dim"] != 16 or
+                self.kplanes_config["grid_dimensions"] != 2 or self.kplanes_config["input_coordinate_dim"] != 4):
+            raise NotImplementedError("libfdgs implements the shipped DyNeRF deformation configuration "
+                                      "(configs/train/dynerf.yaml:85-111): width 128, defor_depth 0/1, two levels, "
+                                      "16 channels, no grid PE / static MLP / empty voxel")
+        self.deformation_net = DeformationNet(self.net_width, self.grid_pe, self.bounds, self.kplanes_config,
+                                              self.multires)
+        self.register_buffer("time_poc", torch.FloatTensor([(2 ** i) for i in range(self.timebase_pe)]))
+        self.register_buffer("pos_poc", torch.FloatTensor([(2 ** i) for i in range(self.posebase_pe)]))
+        self.register_buffer("rotation_scaling_poc",
+                             torch.FloatTensor([(2 ** i) for i in range(self.scale_rotation_pe)]))
+        self.register_buffer("opacity_poc", torch.FloatTensor([(2 ** i) for i in range(self.opacity_pe)]))
+        for m in self.modules():                  # deformation.py:252-258: Xavier weights, default bias
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight, gain=1)
+
+    @property
+    def get_aabb(self):
+        return self.deformation_net.get_aabb
+
+    def forward(self, point, scales=None, rotations=None, opacity=None, shs=None, time=None):
+        return self.forward_dynamic(point, scales, rotations, opacity, shs, time)
+
+    def forward_dynamic(self, point, scales=None, rotations=None, opacity=None, shs=None, time=None):
+        net = self.deformation_net
+        return _DeformFunction.apply(net, point, scales, rotations, opacity, shs, time, *_trainable(net))
+
+    def get_mlp_parameters(self):
+        return self.deformation_net.get_mlp_parameters()
+
+    def get_grid_parameters(self):
+        return self.deformation_net.get_grid_parameters()

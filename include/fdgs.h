@@ -202,10 +202,13 @@ typedef struct {
     /* outputs */
     float* out_xyz; float* out_scales; float* out_rotations; float* out_opacity; float* out_shs;
     /* saved for backward (may be NULL when no gradient is needed):
-     *   hidden [N,128] pre-activation output of feature_out                       */
+     *   hidden [N,128], the pre-activation output of feature_out                   */
     float* save_hidden;
+    void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p) bytes   */
+    size_t workspace_bytes;
 } fdgs_deform_fwd_args;
 
+size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p);
 int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream);
 
 typedef struct {
@@ -214,15 +217,17 @@ typedef struct {
     const float* xyz;
     const float* time; float time_scalar;
     const float* hidden;             /* [N,128] saved by the forward                */
-    const float* g_xyz; const float* g_scales; const float* g_rotations; const float* g_opacity; const float* g_shs; /* output cotangents */
+    /* output cotangents; the residual inputs (scales, rotations, opacity, shs)
+     * receive these unchanged, which the caller does itself                       */
+    const float* g_xyz; const float* g_scales; const float* g_rotations; const float* g_opacity; const float* g_shs;
     /* outputs */
-    float* d_xyz;                    /* [N,3] = g_xyz + d(features)/d(xyz) path     */
-    fdgs_deform_param_grads dp;      /* accumulated into; caller zeroes             */
-    void* workspace;                 /* fdgs_deform_bwd_workspace_bytes(N) bytes    */
+    float* d_xyz;                    /* [N,3] = g_xyz + gradient through the plane coordinates */
+    fdgs_deform_param_grads dp;      /* accumulated into (+=); caller zeroes; entries may be NULL to skip */
+    void* workspace;                 /* fdgs_deform_bwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
 } fdgs_deform_bwd_args;
 
-size_t fdgs_deform_bwd_workspace_bytes(int32_t num_points);
+size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points);
 int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream);
 
 #ifdef __cplusplus
