@@ -129,6 +129,27 @@ def check(status: int, what: str):
         raise RuntimeError(f"{what}: {lib.fdgs_strerror(status).decode()} ({status})")
 
 
+# When set to a dict, every C-ABI call is bracketed by a pair of timing events
+# recorded on the stream the kernels are launched on (name -> [(start, end), ...]).
+PROFILE = None
+
+
+def call(name, args):
+    """Invoke entry point `name` with its argument struct on torch's current stream."""
+    fn = getattr(lib, name)
+    sp = torch.cuda.current_stream().cuda_stream
+    if PROFILE is None:
+        rc = fn(C.byref(args), sp)
+    else:
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(C.byref(args), sp)
+        e.record()
+        PROFILE.setdefault(name, []).append((s, e))
+    check(rc, name)
+
+
 def ptr(t):
     """Device pointer of a contiguous tensor (None -> NULL)."""
     if t is None:

@@ -135,25 +135,30 @@ def _trainable(net):
 class _DeformFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, xyz, scales, rotations, opacity, shs, time, *params):
-        _lib.require_gpu(xyz, scales, rotations, opacity, shs, time, *params)
+        _lib.require_gpu(xyz, scales, rotations, opacity, shs, *params)
         N = xyz.shape[0]
         dev = xyz.device
         c = lambda t: t.detach().to(torch.float32).contiguous()
         xyz_c, sc_c, ro_c, op_c, sh_c = c(xyz), c(scales), c(rotations), c(opacity), c(shs)
-        time_c = c(time).reshape(-1) if time is not None else None
-        if time_c is not None and time_c.numel() != N:
-            raise ValueError("time must have one entry per point")
+        time_scalar = 0.0
+        if isinstance(time, (float, int)):
+            time_scalar, time_c = float(time), None
+        else:
+            time_c = c(time).reshape(-1)
+            if time_c.numel() != N:
+                raise ValueError("time must have one entry per point")
         outs = [torch.empty_like(t) for t in (xyz_c, sc_c, ro_c, op_c, sh_c)]
         need_grad = any(ctx.needs_input_grad)
         hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if need_grad else None
         P = _fill_params(net)
         ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P))
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), 0.0,
+        a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), time_scalar,
                                ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(outs[4]), ptr(hidden),
                                ptr(ws), ws_bytes)
-        check(lib.fdgs_deform_fwd(C.byref(a), stream_ptr()), "fdgs_deform_fwd")
+        _lib.call("fdgs_deform_fwd", a)
         ctx.net = net
+        ctx.time_scalar = time_scalar
         ctx.save_for_backward(xyz_c, time_c, hidden)
         return tuple(outs)
 
@@ -174,9 +179,9 @@ class _DeformFunction(torch.autograd.Function):
         d_xyz = torch.empty_like(xyz_c)
         ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), 0.0, ptr(hidden), ptr(g_xyz), ptr(g_sc), ptr(g_ro),
+        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
-        check(lib.fdgs_deform_bwd(C.byref(a), stream_ptr()), "fdgs_deform_bwd")
+        _lib.call("fdgs_deform_bwd", a)
         pg = tuple(grads[id(p)] for p in params)
         # net, xyz, scales, rotations, opacity, shs, time, *params
         return (None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + pg

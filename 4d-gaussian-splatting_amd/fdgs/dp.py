@@ -1,0 +1,95 @@
+"""View-parallel data parallelism: one process per GPU, replicas of the
+Gaussians / grids / MLP, each rank renders its own views.
+
+The reference has no distributed code; its trainer already loops over a list of
+views and averages one loss over them (src/runner/fdgs_trainer.py:239-248,
+127-130), and that loop is the seam used here.  One exchange step per
+iteration: a single flat-bucket SUM all-reduce of every parameter gradient
+(RCCL over xGMI when the backend is "nccl"), plus three small reductions of the
+densification statistics the trainer keeps (fdgs_trainer.py:125-126,146-148):
+radii MAX, visibility MAX (= OR), summed view-space gradient SUM.
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def rank_world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_views(views, rank=None, world=None):
+    """Rank r takes views r, r+W, r+2W, ... of the global batch."""
+    if rank is None:
+        rank, world = rank_world()
+    return list(views[rank::world])
+
+
+def local_loss_scale(n_local, n_global):
+    """The reference's loss is a mean over the concatenated batch
+    (src/model/losses.py:7-8 via fdgs_trainer.py:495): each rank sums its
+    per-view means scaled by 1/B_global, and the SUM all-reduce of the
+    gradients reproduces the gradient of the global mean."""
+    del n_local
+    return 1.0 / float(n_global)
+
+
+class GradBucket:
+    """Flat fp32 bucket over a fixed parameter list: one collective per step."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def _ensure(self, device):
+        if self.flat is None or self.flat.numel() != self.numel or self.flat.device != device:
+            self.flat = torch.empty(self.numel, device=device, dtype=torch.float32)
+
+    def rebuild(self, params):
+        """After densification / pruning changed N."""
+        self.__init__(params)
+
+    def allreduce_(self, group=None):
+        """SUM all-reduce of every .grad (missing grads count as zero), written back in place."""
+        if not self.params:
+            return
+        self._ensure(self.params[0].device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        if is_dist():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            g = self.flat[off:off + n].view_as(p)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+
+
+def reduce_densification_stats(radii, visibility, viewspace_grad, group=None):
+    """radii [N] int32 -> MAX, visibility [N] bool -> OR, viewspace_grad [N,3] -> SUM (sum, then norm,
+    as fdgs_trainer.py:146-148 + gaussian_model.py:183)."""
+    if not is_dist():
+        return radii, visibility, viewspace_grad
+    r = radii.contiguous()
+    v = visibility.to(torch.uint8).contiguous()
+    g = viewspace_grad.contiguous()
+    dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    return r, v.bool(), g

@@ -33,6 +33,9 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+LAST_NUM_RENDERED = 0     # tile-list length R of the most recent forward (bench bookkeeping)
+
+
 def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
@@ -63,11 +66,13 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
                                ptr(vm), ptr(pm), ptr(cp), ptr(means3D), ptr(scales), ptr(rotations), ptr(opacities),
                                ptr(shs), ptr(st.geom), ptr(st.radii), ptr(st.tiles_touched), ptr(st.point_offsets),
                                ptr(scan_ws))
-    check(lib.fdgs_raster_preprocess_fwd(C.byref(a), sp), "fdgs_raster_preprocess_fwd")
+    _lib.call("fdgs_raster_preprocess_fwd", a)
 
     # the data-dependent list length R: one small device->host read (stream sync)
     R = int(st.point_offsets[-1].item()) if N > 0 else 0
     st.num_rendered = R
+    global LAST_NUM_RENDERED
+    LAST_NUM_RENDERED = R
     keys_a = torch.empty(max(R, 1), device=dev, dtype=torch.int64)
     vals_a = torch.empty(max(R, 1), device=dev, dtype=torch.int32)
     st.keys_sorted = torch.empty(max(R, 1), device=dev, dtype=torch.int64)
@@ -77,7 +82,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     sort_ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     b = _lib.BinSortArgs(N, W, H, R, ptr(st.geom), ptr(st.point_offsets), ptr(keys_a), ptr(vals_a),
                          ptr(st.keys_sorted), ptr(st.vals_sorted), ptr(st.ranges), ptr(sort_ws), ws_bytes)
-    check(lib.fdgs_raster_bin_sort(C.byref(b), sp), "fdgs_raster_bin_sort")
+    _lib.call("fdgs_raster_bin_sort", b)
     if not keep_keys:
         st.keys_sorted = None
 
@@ -87,7 +92,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     st.n_contrib = torch.empty(H, W, device=dev, dtype=torch.int32)
     c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted), ptr(st.geom), ptr(bg), ptr(st.color),
                           ptr(st.depth), ptr(st.final_T), ptr(st.n_contrib))
-    check(lib.fdgs_raster_blend_fwd(C.byref(c), sp), "fdgs_raster_blend_fwd")
+    _lib.call("fdgs_raster_blend_fwd", c)
     return st
 
 
@@ -101,7 +106,7 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S):
     gc = grad_color.to(torch.float32).contiguous()
     a = _lib.BlendBwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted), ptr(st.geom), ptr(bg), ptr(st.final_T),
                           ptr(st.n_contrib), ptr(gc), ptr(dgeom))
-    check(lib.fdgs_raster_blend_bwd(C.byref(a), sp), "fdgs_raster_blend_bwd")
+    _lib.call("fdgs_raster_blend_bwd", a)
     d_means3D = torch.empty(N, 3, device=dev, dtype=torch.float32)
     d_means2D = torch.empty(N, 3, device=dev, dtype=torch.float32)
     d_scales = torch.empty(N, 3, device=dev, dtype=torch.float32)
@@ -112,7 +117,7 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S):
                                float(S.scale_modifier), ptr(vm), ptr(pm), ptr(cp), ptr(means3D), ptr(scales),
                                ptr(rotations), ptr(shs), ptr(st.geom), ptr(dgeom), ptr(d_means3D), ptr(d_means2D),
                                ptr(d_scales), ptr(d_rot), ptr(d_op), ptr(d_shs))
-    check(lib.fdgs_raster_preprocess_bwd(C.byref(b), sp), "fdgs_raster_preprocess_bwd")
+    _lib.call("fdgs_raster_preprocess_bwd", b)
     return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, dgeom
 
 

@@ -1,0 +1,78 @@
+"""Drop-in for `src.gaussian_renderer.render` of the reference
+(src/gaussian_renderer/__init__.py:21-120): same signature, same return dict
+{"render", "viewspace_points", "visibility_filter", "radii", "depth"}.
+
+`pc` is any object with the GaussianModel tensor layout
+(src/model/gaussian_model.py:70-89: get_xyz, _scaling, _rotation, _opacity,
+get_features, active_sh_degree, the three activation callables); `deforms` is
+any object whose `deformation_fields` is callable like DeformationFields.
+"""
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+           stage="fine", cam_type=None, debug=False, convert_SHs_python=False, compute_cov3D_python=False):
+    means3D = pc.get_xyz
+    dev = means3D.device
+    # gradient carrier for the 2-D means (gaussian_renderer/__init__.py:27-31)
+    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=dev) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    if cam_type != "PanopticSports":
+        tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
+        tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
+        raster_settings = GaussianRasterizationSettings(
+            image_height=int(viewpoint_camera.image_height),
+            image_width=int(viewpoint_camera.image_width),
+            tanfovx=tanfovx, tanfovy=tanfovy, bg=bg_color, scale_modifier=scaling_modifier,
+            viewmatrix=viewpoint_camera.world_view_transform.to(dev),
+            projmatrix=viewpoint_camera.full_proj_transform.to(dev),
+            sh_degree=pc.active_sh_degree, campos=viewpoint_camera.camera_center.to(dev),
+            prefiltered=False, debug=debug)
+        time_value = viewpoint_camera.time
+    else:
+        raster_settings = viewpoint_camera["camera"]
+        time_value = viewpoint_camera["time"]
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means2D = screenspace_points
+    opacity = pc._opacity
+    shs = pc.get_features
+    if compute_cov3D_python:
+        raise NotImplementedError("compute_cov3D_python: pass scales/rotations (the rasterizer builds the covariance)")
+    scales = pc._scaling
+    rotations = pc._rotation
+
+    if "coarse" in stage:
+        means3D_final, scales_final, rotations_final, opacity_final, shs_final = means3D, scales, rotations, opacity, shs
+    elif "fine" in stage:
+        # the reference materialises time as an [N,1] tensor (:52); a python float reaches the same
+        # kernel through its scalar-time argument without the N-element allocation
+        means3D_final, scales_final, rotations_final, opacity_final, shs_final = deforms.deformation_fields(
+            means3D, scales, rotations, opacity, shs, float(time_value))
+    else:
+        raise NotImplementedError
+
+    scales_final = pc.scaling_activation(scales_final)
+    rotations_final = pc.rotation_activation(rotations_final)
+    opacity = pc.opacity_activation(opacity_final)
+
+    if override_color is not None or convert_SHs_python:
+        raise NotImplementedError("colors_precomp path (override_color / convert_SHs_python) is not built; "
+                                  "SH evaluation happens inside the rasterizer")
+
+    rendered_image, radii, depth = rasterizer(
+        means3D=means3D_final, means2D=means2D, shs=shs_final, colors_precomp=None, opacities=opacity,
+        scales=scales_final, rotations=rotations_final, cov3D_precomp=None)
+    return {"render": rendered_image,
+            "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0,
+            "radii": radii,
+            "depth": depth}

@@ -1,0 +1,81 @@
+"""One training iteration over a batch of views, mirroring the reference's loop
+body (src/runner/fdgs_trainer.py:112-205): per-view render, L1 loss over the
+batch, backward, view-space gradient / radii / visibility statistics, Adam step
+with the reference's eight parameter groups (:262-274, eps 1e-15).  With
+torch.distributed initialised the views are sharded over ranks and gradients
+and statistics are all-reduced (fdgs.dp)."""
+import torch
+
+from . import dp
+from .renderer import render
+
+
+class DeformHolder:
+    """What render() needs from the reference's DeformationWrapper
+    (src/model/deformation_wrapper.py:9-24): a `deformation_fields` attribute."""
+
+    def __init__(self, deformation_fields):
+        self.deformation_fields = deformation_fields
+
+
+class TrainStep:
+    def __init__(self, gaussians, deforms, background, lr_scale=1.0, stage="fine", fused_adam=True):
+        self.g, self.deforms, self.bg, self.stage = gaussians, deforms, background, stage
+        df = deforms.deformation_fields
+        groups = [   # configs/train/dynerf.yaml:23-35, fdgs_trainer.py:262-272
+            {"params": [gaussians._xyz], "lr": 0.00016 * lr_scale, "name": "xyz"},
+            {"params": list(df.get_mlp_parameters()), "lr": 0.00016 * lr_scale, "name": "deformation"},
+            {"params": list(df.get_grid_parameters()), "lr": 0.0016 * lr_scale, "name": "grid"},
+            {"params": [gaussians._features_dc], "lr": 0.0025, "name": "f_dc"},
+            {"params": [gaussians._features_rest], "lr": 0.0025 / 20.0, "name": "f_rest"},
+            {"params": [gaussians._opacity], "lr": 0.05, "name": "opacity"},
+            {"params": [gaussians._scaling], "lr": 0.005, "name": "scaling"},
+            {"params": [gaussians._rotation], "lr": 0.001, "name": "rotation"},
+        ]
+        on_gpu = gaussians._xyz.is_cuda
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=bool(fused_adam and on_gpu))
+        self.params = [p for grp in groups for p in grp["params"]]
+        self.bucket = dp.GradBucket(self.params)
+        n = gaussians._xyz.shape[0]
+        dev = gaussians._xyz.device
+        self.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
+        self.denom = torch.zeros(n, 1, device=dev)
+        self.max_radii2D = torch.zeros(n, device=dev)
+
+    def __call__(self, global_views):
+        """global_views: the whole batch (identical on every rank); returns the local loss value tensor."""
+        views = dp.shard_views(global_views)
+        scale = dp.local_loss_scale(len(views), len(global_views))
+        radii_list, vis_list, vsp_list = [], [], []
+        loss = None
+        for cam in views:
+            pkg = render(cam, self.g, self.deforms, self.bg, stage=self.stage, cam_type="dynerf")
+            l1 = torch.abs(pkg["render"] - cam.original_image).mean() * scale
+            loss = l1 if loss is None else loss + l1
+            radii_list.append(pkg["radii"])
+            vis_list.append(pkg["visibility_filter"])
+            vsp_list.append(pkg["viewspace_points"])
+        if loss is not None:
+            loss.backward()
+        n = self.g._xyz.shape[0]
+        dev = self.g._xyz.device
+        if views:
+            radii = torch.stack(radii_list, 0).max(dim=0).values
+            vis = torch.stack(vis_list, 0).any(dim=0)
+            vgrad = torch.zeros_like(vsp_list[0])
+            for v in vsp_list:
+                vgrad = vgrad + v.grad
+        else:   # a rank without views this step still takes part in the collectives
+            radii = torch.zeros(n, dtype=torch.int32, device=dev)
+            vis = torch.zeros(n, dtype=torch.bool, device=dev)
+            vgrad = torch.zeros(n, 3, device=dev)
+        if dp.is_dist():
+            self.bucket.allreduce_()
+            radii, vis, vgrad = dp.reduce_densification_stats(radii, vis, vgrad)
+        with torch.no_grad():   # fdgs_trainer.py:181-182, gaussian_model.py:182-184
+            self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis].to(self.max_radii2D.dtype))
+            self.xyz_gradient_accum[vis] += torch.norm(vgrad[vis, :2], dim=-1, keepdim=True)
+            self.denom[vis] += 1
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        return loss.detach() if loss is not None else torch.zeros((), device=dev)

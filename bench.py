@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Benchmark of the 4DGS hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one training iteration of the reference's loop body
+(src/runner/fdgs_trainer.py:112-205) on a synthetic DyNeRF-shaped scene: per
+view  deformation forward -> activations -> rasterizer forward -> L1 loss ->
+backward through both -> densification statistics -> Adam step.  At N GPUs the
+global batch is N views, one per rank (weak scaling), gradients and statistics
+are all-reduced over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "4d-gaussian-splatting_amd"))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=300000)
+    ap.add_argument("--width", type=int, default=1352)
+    ap.add_argument("--height", type=int, default=1014)
+    ap.add_argument("--render-frames", type=int, default=60, help="frames of the inference-only FPS leg (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tile-stride", type=int, default=48, help="cpu baseline blends every k-th tile")
+    return ap.parse_args()
+
+
+def build_scene(args, dev):
+    from fdgs import scene_synth as ss
+    from fdgs.deformation import DeformationFields
+    from fdgs.renderer import render
+    from fdgs.train_step import DeformHolder
+    g = ss.GaussianParams(args.gaussians, device=dev)
+    net = DeformationFields(ss.DYNERF_NET_KWARGS)
+    ss.perturb_deformation_(net)
+    net = net.to(dev)
+    with torch.no_grad():
+        xyz = g._xyz.detach()
+        net.deformation_net.set_aabb(xyz.max(0).values.tolist(), xyz.min(0).values.tolist())   # scene.py:26-33
+    deforms = DeformHolder(net)
+    cams = ss.make_cameras(21, args.width, args.height, device=dev)
+    bg = torch.ones(3, device=dev)            # white_background: true (dynerf.yaml:57)
+    # ground truth: a render of a second, differently seeded scene (dense L1 gradients)
+    g2 = ss.GaussianParams(args.gaussians, seed=ss.SEED + 100, device=dev, requires_grad=False)
+    with torch.no_grad():
+        for cam in cams:
+            cam.original_image = render(cam, g2, deforms, bg, stage="coarse")["render"].clamp(0, 1).clone()
+    del g2
+    return g, net, deforms, cams, bg
+
+
+def cpu_baseline(args, g, net, cam, bg):
+    """The CPU oracle (oracle/deform_ref.py + oracle/raster_ref.py, torch CPU) on the same inputs:
+    deformation forward+backward on all points, rasterizer preprocess/sort on all points, blending
+    forward+backward on every k-th tile, extrapolated by the number of pixel-Gaussian pairs."""
+    from oracle import deform_ref, raster_ref as rr
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cores = torch.get_num_threads()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for k in sd:
+        if k.startswith("deformation_net.") and not k.endswith("aabb"):
+            sd[k].requires_grad_(True)
+    ins = [t.detach().cpu().requires_grad_(True) for t in (g._xyz, g._scaling, g._rotation, g._opacity)]
+    shs = g.get_features.detach().cpu().requires_grad_(True)
+    N = ins[0].shape[0]
+    S = rr.Settings(args.height, args.width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg.cpu(), 1.0,
+                    cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(), 3, cam.camera_center.cpu())
+    gt = cam.original_image.cpu()
+    t0 = time.time()
+    pts, sc, ro, op, sh = deform_ref.deform_forward(sd, ins[0], ins[1], ins[2], ins[3], shs,
+                                                    torch.full((N, 1), float(cam.time)))
+    t_def_f = time.time() - t0
+    m2 = torch.zeros(N, 3, requires_grad=True)
+    t0 = time.time()
+    pre = rr.preprocess(pts, torch.exp(sc), torch.nn.functional.normalize(ro), torch.sigmoid(op), sh, S, m2)
+    keys, vals, _ = rr.build_keys(pre, S)
+    skeys, svals = rr.sort_keys(keys, vals)
+    gx, gy = rr.tile_grid(S)
+    ranges = rr.tile_ranges(skeys, gx * gy)
+    t_pre = time.time() - t0
+    tiles = list(range(0, gx * gy, args.cpu_tile_stride))
+    lens = (ranges[:, 1] - ranges[:, 0]).to(torch.float64)
+    frac = float(lens[tiles].sum() / max(float(lens.sum()), 1.0))
+    t0 = time.time()
+    color, _, _, _ = rr.blend(pre, svals, ranges, S, tiles)
+    t_blend_f = time.time() - t0
+    mask = torch.zeros(gy * 16, gx * 16, dtype=torch.bool)
+    for t in tiles:
+        ty, tx = divmod(t, gx)
+        mask[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    mask = mask[:args.height, :args.width]
+    loss = (torch.abs(color - gt) * mask).sum() / (3.0 * args.height * args.width)
+    mids = [pre[k] for k in ("px", "py", "conA", "conB", "conC", "opacity", "rgb")]
+    t0 = time.time()
+    gmid = torch.autograd.grad(loss, mids, retain_graph=True)     # blending backward, sampled tiles only
+    t_blend_b = time.time() - t0
+    t0 = time.time()
+    torch.autograd.backward(mids, gmid)                            # preprocess + deformation backward, all points
+    t_rest_b = time.time() - t0
+    est = t_def_f + t_pre + (t_blend_f + t_blend_b) / max(frac, 1e-9) + t_rest_b
+    measured = t_def_f + t_pre + t_blend_f + t_blend_b + t_rest_b
+    return {"value": 1.0 / est, "unit": "it/s", "cores": cores, "kind": "port",
+            "sample": (f"deformation fwd+bwd and rasterizer preprocess/sort on all {N} points; blending fwd+bwd on "
+                       f"every {args.cpu_tile_stride}th tile ({len(tiles)} of {gx * gy} tiles, {frac:.4f} of the "
+                       f"tile-list entries), blending time divided by that fraction; measured {measured:.1f} s"),
+            "seconds_measured": measured, "estimated_step_seconds": est}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from fdgs import _lib, rasterizer
+    from fdgs.renderer import render
+    from fdgs.train_step import TrainStep
+
+    g, net, deforms, cams, bg = build_scene(args, dev)
+    step = TrainStep(g, deforms, bg)
+    train_cams = cams[:20]
+
+    def batch(i):
+        return [train_cams[(i * world + r) % len(train_cams)] for r in range(world)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(batch(i))
+    sync()
+    _lib.PROFILE = {}
+    rendered = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(batch(args.warmup + i))
+        rendered.append(rasterizer.LAST_NUM_RENDERED)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof, _lib.PROFILE = _lib.PROFILE, None
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # inference-only leg: deformation + forward rasterizer, frames strided over ranks, no collective
+    fps = None
+    if args.render_frames > 0:
+        frames = list(range(rank, args.render_frames, world))
+        with torch.no_grad():
+            render(cams[20], g, deforms, bg)
+            sync()
+            t1 = time.perf_counter()
+            for f in frames:
+                cams[20].time = f / 300.0
+                render(cams[20], g, deforms, bg)
+            sync()
+            dt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        fps = args.render_frames / dt
+
+    if rank == 0:
+        def avg_ms(name):
+            ev = prof.get(name, [])
+            return sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+        per_call = {k: round(avg_ms(k), 4) for k in prof}
+        R = sum(rendered) / max(len(rendered), 1)
+        px = args.width * args.height
+        # blend backward: 44 B per list entry read + 20 B per pixel read + 40 B per entry of gradient accumulation
+        alg_bytes = 84.0 * R + 20.0 * px
+        dur = avg_ms("fdgs_raster_blend_bwd") * 1e-3
+        achieved = alg_bytes / dur / 1e9 if dur > 0 else 0.0
+        out = {
+            "metric": "train it/s", "value": world * args.steps / elapsed, "unit": "it/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: DyNeRF-shaped synthetic scene, single-view training step "
+                                   "per GPU (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + Adam)",
+                       "gaussians": args.gaussians, "image": [args.width, args.height], "sh_degree": 3,
+                       "global_batch_views": world, "views_per_gpu": 1, "tile_list_entries": R,
+                       "parallelism": f"dp{world}"},
+            "render_fps": fps,
+            "kernel_ms": per_call,
+            "roofline": {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dur * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, g, net, train_cams[0], bg)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
