@@ -30,8 +30,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 #define TILE_PTS 128                     // points per workgroup (4 waves x 32)
 #define LDS_FLOATS (DW * WSTRIDE)        // 16896 floats = 67584 bytes
 
-__device__ __constant__ int c_plane_a[6] = {0, 0, 0, 1, 1, 2};   // itertools.combinations(range(4), 2)
-__device__ __constant__ int c_plane_b[6] = {1, 2, 3, 2, 3, 3};   // (src/model/hexplane.py:96-97)
+// plane ci pairs axes (a,b) = itertools.combinations(range(4), 2)[ci]  (src/model/hexplane.py:96-97):
+// (0,1) (0,2) (0,3) (1,2) (1,3) (2,3).  constexpr so that unrolled loops index registers statically.
+__host__ __device__ __forceinline__ constexpr int plane_a(int ci) { return ci < 3 ? 0 : (ci < 5 ? 1 : 2); }
+__host__ __device__ __forceinline__ constexpr int plane_b(int ci) {
+    return ci == 0 ? 1 : ci == 1 ? 2 : ci == 2 ? 3 : ci == 3 ? 2 : 3;
+}
 
 __device__ __forceinline__ int drow(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -137,7 +141,7 @@ __device__ __forceinline__ void level_features(const PlaneSet& ps, int h, const 
     for (int ch = 0; ch < DF; ++ch) feat[ch] = 1.0f;
 #pragma unroll
     for (int ci = 0; ci < 6; ++ci) {
-        const int a = c_plane_a[ci], b = c_plane_b[ci];
+        const int a = plane_a(ci), b = plane_b(ci);
         const int Wd = h ? ps.res[1][a] : ps.res[0][a];
         const int Hd = h ? ps.res[1][b] : ps.res[0][b];
         const float4* __restrict__ pl = reinterpret_cast<const float4*>(h ? ps.pl[1][ci] : ps.pl[0][ci]);
@@ -226,6 +230,7 @@ struct DeformFwdK {
     float* save_hidden;
 };
 
+// two workgroups per CU: one stages weights while the other issues MFMAs
 __global__ void __launch_bounds__(256, 2)
 deform_fwd_kernel(DeformFwdK a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -324,11 +329,9 @@ static bool params_ok(const fdgs_deform_params* p) {
     return true;
 }
 
-static const int h_plane_a[6] = {0, 0, 0, 1, 1, 2};
-static const int h_plane_b[6] = {1, 2, 3, 2, 3, 3};
 
 static size_t plane_texels(const fdgs_deform_params* p, int l, int ci) {
-    return (size_t)p->res[l][h_plane_a[ci]] * (size_t)p->res[l][h_plane_b[ci]];
+    return (size_t)p->res[l][plane_a(ci)] * (size_t)p->res[l][plane_b(ci)];
 }
 static size_t total_plane_floats(const fdgs_deform_params* p) {
     size_t t = 0;
@@ -404,19 +407,15 @@ extern "C" int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream) {
 // two 128-byte row segments per wave instruction.
 struct DeformBwdK {
     int n;
-    PlaneSet ps;
-    float* gpl[2][6];                    // channel-last plane gradient accumulators
-    const float* aabb;
     const float* w0;
     const float* w1[5]; const float* b1[5]; const float* w2[5];
-    const float* xyz; const float* time; float time_scalar;
     const float* hidden;
     const float* g[5];                   // output cotangents
-    float* d_xyz;
-    float* ws_a1; float* ws_dh1; float* ws_dhid; float* ws_feat;
+    float* ws_a1; float* ws_dh1; float* ws_dhid; float* ws_df;
 };
 
-__global__ void __launch_bounds__(256, 2)
+// one wave per SIMD: the backward keeps three 64-register accumulator tiles live (no spills at 512 registers)
+__global__ void __launch_bounds__(256, 1)
 deform_bwd_points_kernel(DeformBwdK a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -540,70 +539,165 @@ deform_bwd_points_kernel(DeformBwdK a) {
             }
     }
 
-    // HexPlane backward for level h of point c
-    float co[4], sc3[3], feat[DF];
-    float vals[6][DF];
-    point_coords(a.xyz, a.aabb, a.time, a.time_scalar, pc, co, sc3);
-    level_features(a.ps, h, co, feat, vals);
     if (pvalid) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(a.ws_feat + (size_t)p * 32 + 16 * h + 4 * q) =
-                make_float4(feat[4 * q], feat[4 * q + 1], feat[4 * q + 2], feat[4 * q + 3]);
+            *reinterpret_cast<float4*>(a.ws_df + (size_t)p * 32 + 16 * h + 4 * q) =
+                make_float4(df[4 * q], df[4 * q + 1], df[4 * q + 2], df[4 * q + 3]);
     }
-    float dco[3] = {0.f, 0.f, 0.f};
+}
+
+// ---------------------------------------------------------------------------
+// Pass 1b: HexPlane backward.  Item = (point, level); 16 lanes per item, lane =
+// channel, so that every texel access of an item is one contiguous 64-byte
+// segment: four items per wave instruction for loads and for the float atomics
+// of the scatter.  Planes with a time axis are touched in two rows only when
+// the whole call shares one time stamp; those rows are accumulated in LDS and
+// flushed once per workgroup.
+// ---------------------------------------------------------------------------
+struct HexBwdK {
+    int n;
+    PlaneSet ps;
+    float* gpl[2][6];
+    const float* aabb;
+    const float* xyz; const float* time; float time_scalar;
+    const float* ws_df;                  // [N,32] dL/dfeature
+    float* ws_feat;                      // [N,32] features (for the first Linear's weight gradient)
+    const float* g_xyz; float* d_xyz;
+    int lds_time;                        // 1: one time stamp for all points, time-plane rows live in LDS
+};
+
+template <int CTRL>
+__device__ __forceinline__ float row_shr_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
+    return v + __int_as_float(t);
+}
+// sum over the 16 lanes of a DPP row, valid in lane 15 of the row
+__device__ __forceinline__ float row_sum15(float v) {
+    v = row_shr_add<0x111>(v); v = row_shr_add<0x112>(v); v = row_shr_add<0x114>(v); v = row_shr_add<0x118>(v);
+    return v;
+}
+
+#define HEX_LDS_FLOATS (3 * 2 * 64 * DF + 3 * 2 * 128 * DF)   // upper bound used for static sizing below
+
+__global__ void __launch_bounds__(256)
+hexplane_bwd_kernel(HexBwdK a, int lds_floats) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int ch = lane & 15, sub = lane >> 4;
+    if (a.lds_time) {
+        for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) lds[i] = 0.0f;
+        __syncthreads();
+    }
+    // LDS offsets of the three time planes (ci = 2, 4, 5) of each level: [2 rows][res_a][16]
+    int lds_base[2][3];
+    {
+        int off = 0;
 #pragma unroll
-    for (int ci = 0; ci < 6; ++ci) {
-        const int ax = c_plane_a[ci], bx = c_plane_b[ci];
-        const int Wd = h ? a.ps.res[1][ax] : a.ps.res[0][ax];
-        const int Hd = h ? a.ps.res[1][bx] : a.ps.res[0][bx];
-        const float4* __restrict__ pl = reinterpret_cast<const float4*>(h ? a.ps.pl[1][ci] : a.ps.pl[0][ci]);
-        float* __restrict__ gp = h ? a.gpl[1][ci] : a.gpl[0][ci];
-        const Bilinear bl = make_bilinear(co[ax], co[bx], Wd, Hd);
-        float gx = 0.f, gy = 0.f;
+        for (int l = 0; l < 2; ++l)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float gv[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int ch = 4 * q + kk;
-                float pr = df[ch];
-#pragma unroll
-                for (int cj = 0; cj < 6; ++cj)
-                    if (cj != ci) pr *= vals[cj][ch];
-                gv[kk] = pvalid ? pr : 0.0f;
+            for (int tp = 0; tp < 3; ++tp) {
+                lds_base[l][tp] = off;
+                off += 2 * a.ps.res[l][tp] * DF;      // spatial axis of time plane tp is axis tp (x,y,z)
             }
-            const float4 t00 = pl[(size_t)bl.o00 * 4 + q], t01 = pl[(size_t)bl.o01 * 4 + q];
-            const float4 t10 = pl[(size_t)bl.o10 * 4 + q], t11 = pl[(size_t)bl.o11 * 4 + q];
-            const float t00v[4] = {t00.x, t00.y, t00.z, t00.w}, t01v[4] = {t01.x, t01.y, t01.z, t01.w};
-            const float t10v[4] = {t10.x, t10.y, t10.z, t10.w}, t11v[4] = {t11.x, t11.y, t11.z, t11.w};
+    }
+    const int n_items = 2 * a.n;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int base = wave_global * 4; base < n_items; base += n_waves * 4) {
+        const int item = base + sub;
+        const bool valid = item < n_items;
+        const int p = valid ? (item >> 1) : (a.n - 1);
+        const int h = item & 1;
+        float co[4], sc3[3];
+        point_coords(a.xyz, a.aabb, a.time, a.time_scalar, p, co, sc3);
+        float v[6];
+        Bilinear bl[6];
+        float t00[6], t01[6], t10[6], t11[6];
+        float feat = 1.0f;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                gx += gv[kk] * ((t01v[kk] - t00v[kk]) * (1.0f - bl.fy) + (t11v[kk] - t10v[kk]) * bl.fy);
-                gy += gv[kk] * ((t10v[kk] - t00v[kk]) * (1.0f - bl.fx) + (t11v[kk] - t01v[kk]) * bl.fx);
-            }
-            if (pvalid) {
+        for (int ci = 0; ci < 6; ++ci) {
+            const int ax = plane_a(ci), bx = plane_b(ci);
+            const int Wd = h ? a.ps.res[1][ax] : a.ps.res[0][ax];
+            const int Hd = h ? a.ps.res[1][bx] : a.ps.res[0][bx];
+            const float* __restrict__ pl = h ? a.ps.pl[1][ci] : a.ps.pl[0][ci];
+            bl[ci] = make_bilinear(co[ax], co[bx], Wd, Hd);
+            t00[ci] = pl[(size_t)bl[ci].o00 * DF + ch]; t01[ci] = pl[(size_t)bl[ci].o01 * DF + ch];
+            t10[ci] = pl[(size_t)bl[ci].o10 * DF + ch]; t11[ci] = pl[(size_t)bl[ci].o11 * DF + ch];
+            v[ci] = t00[ci] * bl[ci].w00 + t01[ci] * bl[ci].w01 + t10[ci] * bl[ci].w10 + t11[ci] * bl[ci].w11;
+            feat *= v[ci];
+        }
+        float dfv = 0.0f;
+        if (valid) {
+            a.ws_feat[(size_t)p * 32 + 16 * h + ch] = feat;
+            dfv = a.ws_df[(size_t)p * 32 + 16 * h + ch];
+        }
+        float dco[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int ch = 4 * q + kk;
-                    atomicAdd(gp + (size_t)bl.o00 * DF + ch, gv[kk] * bl.w00);
-                    atomicAdd(gp + (size_t)bl.o01 * DF + ch, gv[kk] * bl.w01);
-                    atomicAdd(gp + (size_t)bl.o10 * DF + ch, gv[kk] * bl.w10);
-                    atomicAdd(gp + (size_t)bl.o11 * DF + ch, gv[kk] * bl.w11);
+        for (int ci = 0; ci < 6; ++ci) {
+            const int ax = plane_a(ci), bx = plane_b(ci);
+            const int Wd = h ? a.ps.res[1][ax] : a.ps.res[0][ax];
+            const int Hd = h ? a.ps.res[1][bx] : a.ps.res[0][bx];
+            float g = dfv;
+#pragma unroll
+            for (int cj = 0; cj < 6; ++cj)
+                if (cj != ci) g *= v[cj];
+            const Bilinear& b = bl[ci];
+            const float gx = g * ((t01[ci] - t00[ci]) * (1.0f - b.fy) + (t11[ci] - t10[ci]) * b.fy);
+            const float gy = g * ((t10[ci] - t00[ci]) * (1.0f - b.fx) + (t11[ci] - t01[ci]) * b.fx);
+            // d(texel coordinate)/d(normalised coordinate) = 0.5*(size-1) where strictly inside
+            if (b.in_x) dco[ax] += gx * (0.5f * (float)(Wd - 1));
+            if (bx < 3 && b.in_y) dco[bx] += gy * (0.5f * (float)(Hd - 1));
+            if (valid) {
+                if (bx == 3 && a.lds_time) {
+                    // time plane: rows y0 / y1 are shared by every point of the call
+                    const int tp = ax;
+                    float* L = lds + (h ? lds_base[1][tp] : lds_base[0][tp]);
+                    const int y0 = b.o00 / Wd, x0 = b.o00 - y0 * Wd, x1 = b.o01 - y0 * Wd;
+                    const int r1 = (b.o10 != b.o00) ? 1 : 0;
+                    atomicAdd(L + (0 * Wd + x0) * DF + ch, g * b.w00);
+                    atomicAdd(L + (0 * Wd + x1) * DF + ch, g * b.w01);
+                    atomicAdd(L + (r1 * Wd + x0) * DF + ch, g * b.w10);
+                    atomicAdd(L + (r1 * Wd + x1) * DF + ch, g * b.w11);
+                } else {
+                    float* __restrict__ gp = h ? a.gpl[1][ci] : a.gpl[0][ci];
+                    atomicAdd(gp + (size_t)b.o00 * DF + ch, g * b.w00);
+                    atomicAdd(gp + (size_t)b.o01 * DF + ch, g * b.w01);
+                    atomicAdd(gp + (size_t)b.o10 * DF + ch, g * b.w10);
+                    atomicAdd(gp + (size_t)b.o11 * DF + ch, g * b.w11);
                 }
             }
         }
-        // d(pixel)/d(normalised coord) = 0.5*(size-1) where the coordinate is strictly inside
-        if (bl.in_x) dco[ax] += gx * (0.5f * (float)(Wd - 1));
-        if (bx < 3 && bl.in_y) dco[bx] += gy * (0.5f * (float)(Hd - 1));
+        // sum over channels (DPP row), then over the two levels of the point (rows 2j and 2j+1)
+        float dx = row_sum15(dco[0] * sc3[0]), dy = row_sum15(dco[1] * sc3[1]), dz = row_sum15(dco[2] * sc3[2]);
+        dx += __shfl_xor(dx, 16); dy += __shfl_xor(dy, 16); dz += __shfl_xor(dz, 16);
+        if (valid && h == 0 && ch == 15) {
+            a.d_xyz[3 * (size_t)p + 0] = a.g_xyz[3 * (size_t)p + 0] + dx;
+            a.d_xyz[3 * (size_t)p + 1] = a.g_xyz[3 * (size_t)p + 1] + dy;
+            a.d_xyz[3 * (size_t)p + 2] = a.g_xyz[3 * (size_t)p + 2] + dz;
+        }
     }
-    // both levels of a point live in lanes c and c+32
-    float dx = dco[0] * sc3[0], dy = dco[1] * sc3[1], dz = dco[2] * sc3[2];
-    dx += __shfl_xor(dx, 32); dy += __shfl_xor(dy, 32); dz += __shfl_xor(dz, 32);
-    if (pvalid && h == 0) {
-        a.d_xyz[3 * (size_t)p + 0] = a.g[0][3 * (size_t)p + 0] + dx;
-        a.d_xyz[3 * (size_t)p + 1] = a.g[0][3 * (size_t)p + 1] + dy;
-        a.d_xyz[3 * (size_t)p + 2] = a.g[0][3 * (size_t)p + 2] + dz;
+    if (a.lds_time) {
+        __syncthreads();
+        // flush: LDS row 0 -> plane row y0, LDS row 1 -> plane row y1 of the shared time stamp
+        float x; bool in;
+        unnorm_clip(a.time_scalar, a.ps.res[0][3], x, in);
+        const int y0 = (int)floorf(x), y1 = min(y0 + 1, a.ps.res[0][3] - 1);
+#pragma unroll
+        for (int l = 0; l < 2; ++l)
+#pragma unroll
+            for (int tp = 0; tp < 3; ++tp) {
+                const int ci = tp == 0 ? 2 : tp == 1 ? 4 : 5;
+                const int Wd = a.ps.res[l][tp];
+                float* gp = a.gpl[l][ci];
+                const float* L = lds + lds_base[l][tp];
+                const int row_floats = Wd * DF;
+                for (int i = threadIdx.x; i < row_floats; i += blockDim.x) {
+                    const float v0 = L[i], v1 = L[row_floats + i];
+                    if (v0 != 0.0f) atomicAdd(gp + (size_t)y0 * row_floats + i, v0);
+                    if (v1 != 0.0f) atomicAdd(gp + (size_t)y1 * row_floats + i, v1);
+                }
+            }
     }
 }
 
@@ -644,16 +738,28 @@ deform_wgrad_kernel(WGradK a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
     float bsum = 0.0f;
-    for (int p = p_begin + hh; p < p_end + hh; p += 2) {
-        const bool pv = p < p_end;
-        const float xv = (pv && mv) ? d.X[(size_t)p * d.ldx + m0 + c] : 0.0f;
-        bsum += xv;
+    // 8 K-steps (16 points) per iteration: all loads are issued before the MFMAs that consume them
+    for (int pb = p_begin; pb < p_end; pb += 16) {
+        float xv[8], yv[8][4];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            if (nb < nblk) {
-                float yv = pv ? d.Y[(size_t)p * d.ldy + 32 * nb + c] : 0.0f;
-                if (d.relu_y) yv = fmaxf(yv, 0.0f);
-                acc[nb] = MFMA(xv, yv, acc[nb]);
+        for (int u = 0; u < 8; ++u) {
+            const int p = pb + 2 * u + hh;
+            const bool pv = p < p_end;
+            xv[u] = (pv && mv) ? d.X[(size_t)p * d.ldx + m0 + c] : 0.0f;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+                yv[u][nb] = (pv && nb < nblk) ? d.Y[(size_t)p * d.ldy + 32 * nb + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            bsum += xv[u];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                if (nb < nblk) {
+                    float y = yv[u][nb];
+                    if (d.relu_y) y = fmaxf(y, 0.0f);
+                    acc[nb] = MFMA(xv[u], y, acc[nb]);
+                }
             }
         }
     }
@@ -673,7 +779,7 @@ deform_wgrad_kernel(WGradK a) {
 extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points) {
     if (!p || num_points < 0 || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS) return 0;
     const size_t pf = total_plane_floats(p);
-    const size_t per_point = 640 + 640 + DW + 32;
+    const size_t per_point = 640 + 640 + DW + 32 + 32;
     return (2 * pf + per_point * (size_t)num_points) * sizeof(float);
 }
 
@@ -695,25 +801,28 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     float* ws_dhid = ws_dh1 + (size_t)640 * n;
     float* ws_feat = ws_dhid + (size_t)DW * n;
 
-    DeformBwdK k;
-    k.n = n;
-    int rc = make_plane_set(&a->p, planes_cl, &k.ps, s);
+    float* ws_df = ws_feat + (size_t)32 * n;
+
+    HexBwdK hk;
+    hk.n = n;
+    int rc = make_plane_set(&a->p, planes_cl, &hk.ps, s);
     if (rc != FDGS_OK) return rc;
     if (hipMemsetAsync(grads_cl, 0, pf * sizeof(float), s) != hipSuccess) return FDGS_ELAUNCH;
     {
         size_t off = 0;
         for (int l = 0; l < 2; ++l)
             for (int ci = 0; ci < 6; ++ci) {
-                k.gpl[l][ci] = grads_cl + off;
+                hk.gpl[l][ci] = grads_cl + off;
                 off += plane_texels(&a->p, l, ci) * DF;
             }
     }
-    k.aabb = a->p.aabb; k.w0 = a->p.w0;
+    DeformBwdK k;
+    k.n = n;
+    k.w0 = a->p.w0;
     for (int h = 0; h < 5; ++h) { k.w1[h] = a->p.w1[h]; k.b1[h] = a->p.b1[h]; k.w2[h] = a->p.w2[h]; }
-    k.xyz = a->xyz; k.time = a->time; k.time_scalar = a->time_scalar; k.hidden = a->hidden;
+    k.hidden = a->hidden;
     k.g[0] = a->g_xyz; k.g[1] = a->g_scales; k.g[2] = a->g_rotations; k.g[3] = a->g_opacity; k.g[4] = a->g_shs;
-    k.d_xyz = a->d_xyz;
-    k.ws_a1 = ws_a1; k.ws_dh1 = ws_dh1; k.ws_dhid = ws_dhid; k.ws_feat = ws_feat;
+    k.ws_a1 = ws_a1; k.ws_dh1 = ws_dh1; k.ws_dhid = ws_dhid; k.ws_df = ws_df;
     const int blocks = (n + TILE_PTS - 1) / TILE_PTS;
     const size_t lds_bytes = LDS_FLOATS * sizeof(float);
     if (hipFuncSetAttribute((const void*)deform_bwd_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -721,6 +830,28 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         return FDGS_ELAUNCH;
     hipLaunchKernelGGL(deform_bwd_points_kernel, dim3(blocks), dim3(256), lds_bytes, s, k);
     FDGS_CHECK_LAUNCH();
+
+    // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
+    hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
+    hk.ws_df = ws_df; hk.ws_feat = ws_feat; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
+    hk.lds_time = (a->time == nullptr) ? 1 : 0;
+    int hex_lds_floats = 0;
+    for (int l = 0; l < 2; ++l)
+        for (int tp = 0; tp < 3; ++tp) hex_lds_floats += 2 * a->p.res[l][tp] * DF;
+    if ((size_t)hex_lds_floats * sizeof(float) > 150 * 1024) { hk.lds_time = 0; }
+    const size_t hex_lds_bytes = hk.lds_time ? (size_t)hex_lds_floats * sizeof(float) : 0;
+    if (hex_lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)hexplane_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)hex_lds_bytes) != hipSuccess)
+        return FDGS_ELAUNCH;
+    {
+        const long long waves_needed = ((long long)2 * n + 3) / 4;
+        long long hb = (waves_needed + 3) / 4;
+        if (hb > 512) hb = 512;
+        if (hb < 1) hb = 1;
+        hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)hb), dim3(256), hex_lds_bytes, s, hk, hex_lds_floats);
+        FDGS_CHECK_LAUNCH();
+    }
 
     // weight gradients
     static const int kdim[5] = {3, 3, 4, 1, 48};
@@ -758,7 +889,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             if (!a->dp.planes[l][ci]) continue;
             const int hw = (int)plane_texels(&a->p, l, ci);
             hipLaunchKernelGGL(planes_grad_from_channel_last_kernel, dim3((hw + 255) / 256), dim3(256), 0, s,
-                               k.gpl[l][ci], a->dp.planes[l][ci], hw);
+                               hk.gpl[l][ci], a->dp.planes[l][ci], hw);
             FDGS_CHECK_LAUNCH();
         }
     return FDGS_OK;

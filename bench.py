@@ -196,6 +196,13 @@ def main():
         alg_bytes = 84.0 * R + 20.0 * px
         dur = avg_ms("fdgs_raster_blend_bwd") * 1e-3
         achieved = alg_bytes / dur / 1e9 if dur > 0 else 0.0
+        # HBM traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # summarised by tools/pmc_summary.py into profiles/); only valid for the default workload
+        traffic = None
+        if (args.gaussians, args.width, args.height) == (300000, 1352, 1014):
+            import glob
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
+                traffic = json.load(open(f)).get("blend_bwd_kernel", {}).get("traffic_bytes_per_launch")
         out = {
             "metric": "train it/s", "value": world * args.steps / elapsed, "unit": "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -209,7 +216,7 @@ def main():
             "render_fps": fps,
             "kernel_ms": per_call,
             "roofline": {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dur * 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:

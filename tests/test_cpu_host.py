@@ -1,0 +1,103 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol
+include/fdgs.h declares, argument validation works without touching a device,
+the synthetic scene generator follows the reference's camera conventions, the
+drop-in module keeps the reference's state_dict layout, and the product code
+never imports the oracle."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from fdgs import _lib
+    header = open(os.path.join(ROOT, "include", "fdgs.h")).read()
+    declared = set(re.findall(r"\b(fdgs_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations found"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert getattr(_lib.lib, name) is not None
+    assert _lib.lib.fdgs_abi_version() == _lib.ABI_VERSION
+    assert _lib.lib.fdgs_strerror(0) == b"ok"
+    assert b"workspace" in _lib.lib.fdgs_strerror(-3)
+
+
+def test_argument_validation_without_device():
+    """Null / negative arguments are rejected before any launch (no GPU needed)."""
+    from fdgs import _lib
+    a = _lib.PreprocessFwdArgs()
+    a.num_points = -1
+    assert _lib.lib.fdgs_raster_preprocess_fwd(C.byref(a), None) == -1
+    a.num_points, a.image_width, a.image_height, a.sh_degree = 10, 64, 64, 7
+    assert _lib.lib.fdgs_raster_preprocess_fwd(C.byref(a), None) == -1
+    a.sh_degree = 3          # pointers still null
+    assert _lib.lib.fdgs_raster_preprocess_fwd(C.byref(a), None) == -1
+    b = _lib.BlendFwdArgs()
+    assert _lib.lib.fdgs_raster_blend_fwd(C.byref(b), None) == -1
+    d = _lib.DeformFwdArgs()
+    d.num_points = 5
+    assert _lib.lib.fdgs_deform_fwd(C.byref(d), None) == -1      # num_levels == 0
+    assert _lib.lib.fdgs_raster_sort_workspace_bytes(1000) >= 256 * 4
+    assert _lib.lib.fdgs_raster_scan_workspace_bytes(300000) >= 4
+
+
+def test_cpu_tensors_are_refused():
+    from fdgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    S = GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.ones(3), 1.0, torch.eye(4), torch.eye(4), 3,
+                                      torch.zeros(3), False, False)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        GaussianRasterizer(S)(means3D=torch.zeros(4, 3), means2D=torch.zeros(4, 3), shs=torch.zeros(4, 16, 3),
+                              colors_precomp=None, opacities=torch.ones(4, 1), scales=torch.ones(4, 3),
+                              rotations=torch.ones(4, 4), cov3D_precomp=None)
+
+
+def test_deformation_module_state_dict_layout():
+    """39 keys, names and shapes of the reference's DeformationFields (fixture recorded from the reference)."""
+    import deform_cases as dc
+    from fdgs.deformation import DeformationFields
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "deform_dynerf.npz"))
+    net = DeformationFields(dc.net_kwargs("dynerf"))
+    sd = net.state_dict()
+    assert sorted(sd.keys()) == sorted(gold["state_keys"].tolist())
+    assert len(sd) == 39
+    ref_sd = dc.make_state("dynerf")
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref_sd[k].shape), k
+    g = net.deformation_net.grid.grids
+    assert float(g[0][2].detach().min()) == 1.0 == float(g[0][2].detach().max())   # time planes start at one
+    assert 0.1 <= float(g[0][0].detach().min()) and float(g[0][0].detach().max()) <= 0.5
+    net.load_state_dict(ref_sd)
+    assert len(net.get_grid_parameters()) == 13 and len(net.get_mlp_parameters()) == 22   # aabb counts as "grid"
+    net.deformation_net.set_aabb([1, 2, 3], [-1, -2, -3])
+    assert net.get_aabb[0].tolist() == [1, 2, 3] and not net.deformation_net.grid.aabb.requires_grad
+    assert tuple(g[0][2].shape) == (1, 16, 150, 64) and tuple(g[1][0].shape) == (1, 16, 128, 128)
+
+
+def test_synthetic_cameras_follow_reference_conventions():
+    from fdgs import scene_synth as ss
+    from oracle import raster_ref as rr
+    cams = ss.make_cameras(5, 1352, 1014)
+    for cam in cams:
+        wvt, full, center = rr.camera_tensors(cam.R, cam.T, cam.FoVx, cam.FoVy)
+        assert torch.allclose(cam.world_view_transform, wvt, atol=1e-6)
+        assert torch.allclose(cam.full_proj_transform, full, atol=1e-5)
+        assert torch.allclose(cam.camera_center, center, atol=1e-5)
+        # the scene origin is in front of the camera and projects to the image centre
+        p = torch.tensor([0.0, 0.0, 0.0, 1.0]) @ cam.full_proj_transform
+        assert p[3] > 0.2 and abs(float(p[0] / p[3])) < 1e-4 and abs(float(p[1] / p[3])) < 1e-4
+    assert abs(math.degrees(cams[0].FoVx) - 85.6) < 0.2 and 0.0 <= cams[3].time < 1.0
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "4d-gaussian-splatting_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text, f"{f} mentions the oracle"

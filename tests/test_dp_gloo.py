@@ -1,0 +1,94 @@
+"""World-size-2 gloo test (CPU) of the data-parallel exchange step: view
+sharding, the flat gradient bucket SUM all-reduce and the three densification
+statistics reductions must reproduce the 1-rank result on the same global batch."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _toy_problem():
+    """Stand-in for render(): a differentiable per-view function of shared parameters
+    (the collectives do not care what produced the gradients)."""
+    g = torch.Generator().manual_seed(3)
+    params = [torch.randn(50, 3, generator=g).requires_grad_(True),
+              torch.randn(7, generator=g).requires_grad_(True),
+              torch.randn(4, 5, generator=g).requires_grad_(True),
+              torch.randn(3, generator=g).requires_grad_(True)]       # never used: grad stays None
+    views = [torch.randn(50, 3, generator=g) for _ in range(4)]
+    return params, views
+
+
+def _view_loss(params, view):
+    return ((params[0] * view).sum(dim=1).tanh().mean() + (params[1] ** 2).sum() * view.mean()
+            + (params[2].sum() * view[0, 0]))
+
+
+def _view_stats(view):
+    radii = (view[:, 0] * 10).to(torch.int32).clamp(min=0)
+    vis = radii > 0
+    vgrad = view * 0.1
+    return radii, vis, vgrad
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "4d-gaussian-splatting_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from fdgs import dp
+    params, views = _toy_problem()
+    mine = dp.shard_views(views)
+    assert len(mine) == len(views) // world
+    scale = dp.local_loss_scale(len(mine), len(views))
+    loss = sum(_view_loss(params, v) for v in mine) * scale
+    loss.backward()
+    bucket = dp.GradBucket(params)
+    bucket.allreduce_()
+    stats = [_view_stats(v) for v in mine]
+    radii = torch.stack([s[0] for s in stats]).max(0).values
+    vis = torch.stack([s[1] for s in stats]).any(0)
+    vgrad = sum(s[2] for s in stats)
+    radii, vis, vgrad = dp.reduce_densification_stats(radii, vis, vgrad)
+    if rank == 0:
+        torch.save({"grads": [p.grad for p in params], "radii": radii, "vis": vis, "vgrad": vgrad}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_one_rank(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    params, views = _toy_problem()
+    loss = sum(_view_loss(params, v) for v in views) / len(views)
+    loss.backward()
+    for p, g in zip(params, got["grads"]):
+        ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(g, ref, rtol=1e-5, atol=1e-7)
+    stats = [_view_stats(v) for v in views]
+    assert torch.equal(got["radii"], torch.stack([s[0] for s in stats]).max(0).values)      # integer: bitwise
+    assert torch.equal(got["vis"], torch.stack([s[1] for s in stats]).any(0))
+    assert torch.allclose(got["vgrad"], sum(s[2] for s in stats), rtol=1e-5, atol=1e-7)
+
+
+def test_shard_views_partition():
+    sys.path.insert(0, os.path.join(ROOT, "4d-gaussian-splatting_amd"))
+    from fdgs import dp
+    views = list(range(8))
+    for world in (1, 2, 4, 8):
+        parts = [dp.shard_views(views, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == views and all(len(p) == 8 // world for p in parts)
