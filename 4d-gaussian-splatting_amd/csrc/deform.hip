@@ -48,32 +48,48 @@ __device__ __forceinline__ T sel5(const T* v, int i) {
 __device__ __forceinline__ int head_dim(int head) { return head == 0 ? 3 : head == 1 ? 3 : head == 2 ? 4 : head == 3 ? 1 : 48; }
 
 // ---------------------------------------------------------------------------
-// [16][H][W] -> [H][W][16]   and the reverse, accumulating (+=)
+// [16][H][W] -> [H][W][16] for all twelve planes in one launch, and the reverse
+// (accumulating, +=) for the gradients.  blockIdx.y selects the plane.
 // ---------------------------------------------------------------------------
+struct PlaneTable {
+    const float* src[12];
+    float* dst[12];
+    int hw[12];
+};
+
 __global__ void __launch_bounds__(256)
-planes_to_channel_last_kernel(const float* __restrict__ src, float* __restrict__ dst, int hw) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= hw) return;
-    float v[DF];
+planes_to_channel_last_kernel(PlaneTable t) {
+    const float* __restrict__ src = t.src[0]; float* __restrict__ dst = t.dst[0]; int hw = t.hw[0];
 #pragma unroll
-    for (int ch = 0; ch < DF; ++ch) v[ch] = src[(size_t)ch * hw + t];
-    float4* d = reinterpret_cast<float4*>(dst + (size_t)t * DF);
+    for (int i = 1; i < 12; ++i)
+        if ((int)blockIdx.y == i) { src = t.src[i]; dst = t.dst[i]; hw = t.hw[i]; }
+    for (int tx = blockIdx.x * blockDim.x + threadIdx.x; tx < hw; tx += gridDim.x * blockDim.x) {
+        float v[DF];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) d[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int ch = 0; ch < DF; ++ch) v[ch] = src[(size_t)ch * hw + tx];
+        float4* d = reinterpret_cast<float4*>(dst + (size_t)tx * DF);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
 }
 
 __global__ void __launch_bounds__(256)
-planes_grad_from_channel_last_kernel(const float* __restrict__ src_cl, float* __restrict__ dst, int hw) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= hw) return;
-    const float4* s = reinterpret_cast<const float4*>(src_cl + (size_t)t * DF);
+planes_grad_from_channel_last_kernel(PlaneTable t) {   // src = channel-last gradients, dst = parameter-layout gradients
+    const float* __restrict__ src = t.src[0]; float* __restrict__ dst = t.dst[0]; int hw = t.hw[0];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = s[q];
-        dst[(size_t)(4 * q + 0) * hw + t] += v.x;
-        dst[(size_t)(4 * q + 1) * hw + t] += v.y;
-        dst[(size_t)(4 * q + 2) * hw + t] += v.z;
-        dst[(size_t)(4 * q + 3) * hw + t] += v.w;
+    for (int i = 1; i < 12; ++i)
+        if ((int)blockIdx.y == i) { src = t.src[i]; dst = t.dst[i]; hw = t.hw[i]; }
+    if (!dst) return;
+    for (int tx = blockIdx.x * blockDim.x + threadIdx.x; tx < hw; tx += gridDim.x * blockDim.x) {
+        const float4* s4 = reinterpret_cast<const float4*>(src + (size_t)tx * DF);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = s4[q];
+            dst[(size_t)(4 * q + 0) * hw + tx] += v.x;
+            dst[(size_t)(4 * q + 1) * hw + tx] += v.y;
+            dst[(size_t)(4 * q + 2) * hw + tx] += v.z;
+            dst[(size_t)(4 * q + 3) * hw + tx] += v.w;
+        }
     }
 }
 
@@ -345,19 +361,27 @@ extern "C" size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p) {
     return total_plane_floats(p) * sizeof(float);
 }
 
-// builds the channel-last copies in ws and fills ps
-static int make_plane_set(const fdgs_deform_params* p, float* ws, PlaneSet* ps, hipStream_t s) {
+// fills ps with the channel-last plane addresses inside ws and (unless the caller
+// says ws already holds them) rebuilds the copies with one launch
+static int make_plane_set(const fdgs_deform_params* p, float* ws, PlaneSet* ps, bool rebuild, hipStream_t s) {
+    PlaneTable t;
     size_t off = 0;
+    int max_hw = 0;
     for (int l = 0; l < 2; ++l) {
         for (int k = 0; k < 4; ++k) ps->res[l][k] = p->res[l][k];
         for (int ci = 0; ci < 6; ++ci) {
             const int hw = (int)plane_texels(p, l, ci);
-            hipLaunchKernelGGL(planes_to_channel_last_kernel, dim3((hw + 255) / 256), dim3(256), 0, s, p->planes[l][ci],
-                               ws + off, hw);
-            FDGS_CHECK_LAUNCH();
+            t.src[6 * l + ci] = p->planes[l][ci];
+            t.dst[6 * l + ci] = ws + off;
+            t.hw[6 * l + ci] = hw;
             ps->pl[l][ci] = ws + off;
             off += (size_t)hw * DF;
+            if (hw > max_hw) max_hw = hw;
         }
+    }
+    if (rebuild) {
+        hipLaunchKernelGGL(planes_to_channel_last_kernel, dim3((max_hw + 255) / 256, 12), dim3(256), 0, s, t);
+        FDGS_CHECK_LAUNCH();
     }
     return FDGS_OK;
 }
@@ -372,7 +396,7 @@ extern "C" int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     DeformFwdK k;
     k.n = a->num_points;
-    int rc = make_plane_set(&a->p, (float*)a->workspace, &k.ps, s);
+    int rc = make_plane_set(&a->p, (float*)a->workspace, &k.ps, true, s);
     if (rc != FDGS_OK) return rc;
     k.aabb = a->p.aabb; k.w0 = a->p.w0; k.b0 = a->p.b0;
     for (int h = 0; h < 5; ++h) { k.w1[h] = a->p.w1[h]; k.b1[h] = a->p.b1[h]; k.w2[h] = a->p.w2[h]; k.b2[h] = a->p.b2[h]; }
@@ -805,7 +829,9 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
 
     HexBwdK hk;
     hk.n = n;
-    int rc = make_plane_set(&a->p, planes_cl, &hk.ps, s);
+    const bool reuse = a->planes_channel_last != nullptr;
+    if (reuse) planes_cl = const_cast<float*>(a->planes_channel_last);
+    int rc = make_plane_set(&a->p, planes_cl, &hk.ps, !reuse, s);
     if (rc != FDGS_OK) return rc;
     if (hipMemsetAsync(grads_cl, 0, pf * sizeof(float), s) != hipSuccess) return FDGS_ELAUNCH;
     {
@@ -883,14 +909,20 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     hipLaunchKernelGGL(deform_wgrad_kernel, dim3(chunks, WG_MAX), dim3(256), 0, s, w);
     FDGS_CHECK_LAUNCH();
 
-    // plane gradients back to the parameter layout [16][H][W]
-    for (int l = 0; l < 2; ++l)
-        for (int ci = 0; ci < 6; ++ci) {
-            if (!a->dp.planes[l][ci]) continue;
-            const int hw = (int)plane_texels(&a->p, l, ci);
-            hipLaunchKernelGGL(planes_grad_from_channel_last_kernel, dim3((hw + 255) / 256), dim3(256), 0, s,
-                               hk.gpl[l][ci], a->dp.planes[l][ci], hw);
-            FDGS_CHECK_LAUNCH();
-        }
+    // plane gradients back to the parameter layout [16][H][W] (one launch, += into the caller's buffers)
+    {
+        PlaneTable t;
+        int max_hw = 0;
+        for (int l = 0; l < 2; ++l)
+            for (int ci = 0; ci < 6; ++ci) {
+                const int hw = (int)plane_texels(&a->p, l, ci);
+                t.src[6 * l + ci] = hk.gpl[l][ci];
+                t.dst[6 * l + ci] = a->dp.planes[l][ci];
+                t.hw[6 * l + ci] = hw;
+                if (hw > max_hw) max_hw = hw;
+            }
+        hipLaunchKernelGGL(planes_grad_from_channel_last_kernel, dim3((max_hw + 255) / 256, 12), dim3(256), 0, s, t);
+        FDGS_CHECK_LAUNCH();
+    }
     return FDGS_OK;
 }

@@ -82,7 +82,7 @@ class DeformFwdArgs(C.Structure):
 
 class DeformBwdArgs(C.Structure):
     _fields_ = [("num_points", c_i32), ("p", DeformParams),
-                ("xyz", c_p), ("time", c_p), ("time_scalar", c_f), ("hidden", c_p),
+                ("xyz", c_p), ("time", c_p), ("time_scalar", c_f), ("hidden", c_p), ("planes_channel_last", c_p),
                 ("g_xyz", c_p), ("g_scales", c_p), ("g_rotations", c_p), ("g_opacity", c_p), ("g_shs", c_p),
                 ("d_xyz", c_p), ("dp", DeformParamGrads), ("workspace", c_p), ("workspace_bytes", c_sz)]
 
@@ -104,7 +104,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def _load():

@@ -159,13 +159,14 @@ class _DeformFunction(torch.autograd.Function):
         _lib.call("fdgs_deform_fwd", a)
         ctx.net = net
         ctx.time_scalar = time_scalar
-        ctx.save_for_backward(xyz_c, time_c, hidden)
+        ctx.param_versions = [p._version for p in params]
+        ctx.save_for_backward(xyz_c, time_c, hidden, ws)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_xyz, g_sc, g_ro, g_op, g_sh):
         net = ctx.net
-        xyz_c, time_c, hidden = ctx.saved_tensors
+        xyz_c, time_c, hidden, fwd_ws = ctx.saved_tensors
         N = xyz_c.shape[0]
         dev = xyz_c.device
         c = lambda t, like: (torch.zeros_like(like) if t is None else t.to(torch.float32).contiguous())
@@ -177,9 +178,12 @@ class _DeformFunction(torch.autograd.Function):
         P = _fill_params(net)
         G = _fill_params(net, grads)
         d_xyz = torch.empty_like(xyz_c)
+        # the forward's channel-last plane copies are still valid if no parameter was written since
+        unchanged = all(p._version == v for p, v in zip(params, ctx.param_versions))
+        planes_cl = ptr(fwd_ws) if unchanged else None
         ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(g_xyz), ptr(g_sc), ptr(g_ro),
+        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_bwd", a)
         pg = tuple(grads[id(p)] for p in params)

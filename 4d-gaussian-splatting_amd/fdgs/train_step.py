@@ -72,10 +72,13 @@ class TrainStep:
         if dp.is_dist():
             self.bucket.allreduce_()
             radii, vis, vgrad = dp.reduce_densification_stats(radii, vis, vgrad)
-        with torch.no_grad():   # fdgs_trainer.py:181-182, gaussian_model.py:182-184
-            self.max_radii2D[vis] = torch.max(self.max_radii2D[vis], radii[vis].to(self.max_radii2D.dtype))
-            self.xyz_gradient_accum[vis] += torch.norm(vgrad[vis, :2], dim=-1, keepdim=True)
-            self.denom[vis] += 1
+        with torch.no_grad():   # fdgs_trainer.py:181-182, gaussian_model.py:182-184, written without
+            # boolean indexing (which would synchronise the host on the number of visible points)
+            self.max_radii2D = torch.where(vis, torch.max(self.max_radii2D, radii.to(self.max_radii2D.dtype)),
+                                           self.max_radii2D)
+            visf = vis.unsqueeze(-1).to(self.denom.dtype)
+            self.xyz_gradient_accum += torch.norm(vgrad[:, :2], dim=-1, keepdim=True) * visf
+            self.denom += visf
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach() if loss is not None else torch.zeros((), device=dev)

@@ -217,6 +217,8 @@ typedef struct {
     const float* xyz;
     const float* time; float time_scalar;
     const float* hidden;             /* [N,128] saved by the forward                */
+    const float* planes_channel_last;/* the forward's workspace (channel-last plane copies) if the parameters have
+                                        not changed since, else NULL: the copies are rebuilt inside the workspace */
     /* output cotangents; the residual inputs (scales, rotations, opacity, shs)
      * receive these unchanged, which the caller does itself                       */
     const float* g_xyz; const float* g_scales; const float* g_rotations; const float* g_opacity; const float* g_shs;
