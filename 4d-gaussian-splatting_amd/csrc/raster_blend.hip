@@ -121,6 +121,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return bcast(v, 63);
 }
 
+// x + (the other half-wave's y) arranged so that lanes 0-31 return sum-pairs of a, lanes 32-63 of b
+__device__ __forceinline__ float xswap32_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// same between the 16-lane rows of each half: even rows return pairs of a, odd rows pairs of b
+__device__ __forceinline__ float xswap16_add(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float ror8(float v) {   // lane i reads lane i^8 of its row
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+}
+
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     const int tile = blockIdx.x;
@@ -206,15 +220,23 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
                 v_C = -0.5f * gdy * dy * dL_dG;
                 v_o = G * dL_dalpha;
             }
-            const float s0 = wave_sum(v_mx), s1 = wave_sum(v_my), s2 = wave_sum(v_A), s3 = wave_sum(v_B);
-            const float s4 = wave_sum(v_C), s5 = wave_sum(v_o), s6 = wave_sum(v_r), s7 = wave_sum(v_g);
+            // Eight of the nine partial sums go through a transposing butterfly: each exchange step halves
+            // the number of live registers (v_permlane32_swap / v_permlane16_swap trade one register's upper
+            // half for another's lower half; row_ror:8 does the same inside a 16-lane row), so that the 8-lane
+            // group g = lane>>3 ends up owning the total of value g.  The ninth takes the plain DPP reduction.
+            float t0 = xswap32_add(v_mx, v_C), t1 = xswap32_add(v_my, v_o);   // lanes <32: v[i], >=32: v[i+4]
+            float t2 = xswap32_add(v_A, v_r), t3 = xswap32_add(v_B, v_g);
+            const float u0 = xswap16_add(t0, t2), u1 = xswap16_add(t1, t3);  // rows with bit4: v[i+2]
+            const float a8 = u0 + ror8(u0), b8 = u1 + ror8(u1);
+            float r = (lane & 8) ? b8 : a8;                                   // bit3: v[i+1]
+            r = dpp_add<0x111, 0xf>(r);                                       // sum of each 8-lane group ...
+            r = dpp_add<0x112, 0xf>(r);
+            r = dpp_add<0x114, 0xf>(r);                                       // ... lands in lanes 8g+7
             const float s8 = wave_sum(v_b);
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
-            if (lane < 9) {
-                float v = s0;
-                v = lane == 1 ? s1 : v; v = lane == 2 ? s2 : v; v = lane == 3 ? s3 : v; v = lane == 4 ? s4 : v;
-                v = lane == 5 ? s5 : v; v = lane == 6 ? s6 : v; v = lane == 7 ? s7 : v; v = lane == 8 ? s8 : v;
-                atomicAdd(a.dL_dgeom + (size_t)gid * FDGS_GEOM_FLOATS + lane, v);
+            if ((lane & 7) == 7 || lane == 0) {
+                const int comp = lane == 0 ? 8 : (lane >> 3);
+                atomicAdd(a.dL_dgeom + (size_t)gid * FDGS_GEOM_FLOATS + comp, lane == 0 ? s8 : r);
             }
         }
     }
