@@ -9,8 +9,8 @@
 // A layer Y^T = W X^T therefore takes the previous layer's accumulator registers
 // directly as its B operand (register r of the k-th 32-row block is the K pair
 // {32k+row(r,0), 32k+row(r,1)}), and the weights W[n][k] as the A operand: four
-// consecutive steps r = 4t..4t+3 need W[n][32k + 8t + 4h + 0..3], one 16-byte LDS
-// read from a row-major image padded to a 132-float row stride (conflict-free).
+// consecutive steps r = 4t..4t+3 need W[n][32k + 8t + 4h + 0..3], one 16-byte load
+// from a copy of the weights re-packed in exactly that fragment order.
 //
 // The two halves of a wave also split the HexPlane work: lane (c,h) interpolates
 // the 16 channels of resolution level h for point c, which is exactly the K pair
@@ -25,10 +25,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 #define DW FDGS_DEFORM_WIDTH             // 128
 #define DF FDGS_DEFORM_FEAT              // 16
-#define WSTRIDE 132                      // padded row stride (floats) of a [rows][128] LDS weight image
-#define W0STRIDE 36                      // padded row stride of the [128][32] first-layer image
 #define TILE_PTS 128                     // points per workgroup (4 waves x 32)
-#define LDS_FLOATS (DW * WSTRIDE)        // 16896 floats = 67584 bytes
 
 // plane ci pairs axes (a,b) = itertools.combinations(range(4), 2)[ci]  (src/model/hexplane.py:96-97):
 // (0,1) (0,2) (0,3) (1,2) (1,3) (2,3).  constexpr so that unrolled loops index registers statically.
@@ -181,44 +178,92 @@ __device__ __forceinline__ void level_features(const PlaneSet& ps, int h, const 
 }
 
 // ---------------------------------------------------------------------------
-// LDS staging of row-major weight matrices
+// Weight fragments.  At the start of every call each weight matrix is re-packed
+// (one small launch, 0.4-0.7 MB) into the order the MFMA A operand consumes it:
+// for row block ib (32 output rows) and K group T (8 reduction indices) the 64
+// lanes' float4 are contiguous, lane (c,h) holding element(32 ib + c, kk) for
+// kk = 8T + 4h + q, q = 0..3 (the K pairs {row(r,0), row(r,1)} of four
+// consecutive accumulator registers).  Every A-operand fetch is then one fully
+// coalesced 1-KiB global_load_dwordx4 from L2; no LDS, no workgroup barrier.
 // ---------------------------------------------------------------------------
-// [rows][128] global -> LDS with row stride WSTRIDE; rows [rows, pad_rows) are zero filled.
-__device__ __forceinline__ void stage_w128(float* lds, const float* __restrict__ w, int rows, int pad_rows) {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(w);
-    for (int idx = threadIdx.x; idx < pad_rows * 32; idx += blockDim.x) {
-        const int row = idx >> 5, c4 = idx & 31;
-        const float4 v = row < rows ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(lds + row * WSTRIDE + c4 * 4) = v;
-    }
-}
-// [128][32] global -> LDS with row stride W0STRIDE
-__device__ __forceinline__ void stage_w0(float* lds, const float* __restrict__ w) {
-    const float4* __restrict__ src = reinterpret_cast<const float4*>(w);
-    for (int idx = threadIdx.x; idx < DW * 8; idx += blockDim.x) {
-        const int row = idx >> 3, c4 = idx & 7;
-        *reinterpret_cast<float4*>(lds + row * W0STRIDE + c4 * 4) = src[idx];
+#define FRAG_TRANSPOSE 1     // element(i,kk) = src[kk*ld + i]   (else src[i*ld + kk])
+#define FRAG_FEATMAP 2       // kk = 16h + 4T + q  (first Linear: lane half h owns level h's 16 features)
+#define FRAG_PERMROWS 4      // row i carries column perm(i) = 16*((i>>2)&1) + 4*(i>>3) + (i&3)
+
+struct FragDesc { const float* src; float* dst; int I; int K; int ld; int mode; };
+#define FRAG_MAX 16
+struct FragTable { FragDesc d[FRAG_MAX]; int n; };
+
+__host__ __device__ __forceinline__ int frag_floats(int I, int K) { return ((I + 31) / 32) * ((K + 7) / 8) * 256; }
+
+__global__ void __launch_bounds__(256)
+pack_fragments_kernel(FragTable t) {
+    FragDesc d = t.d[0];
+#pragma unroll
+    for (int i = 1; i < FRAG_MAX; ++i)
+        if ((int)blockIdx.y == i) d = t.d[i];
+    if ((int)blockIdx.y >= t.n) return;
+    const int G = (d.K + 7) / 8, IB = (d.I + 31) / 32;
+    const int total = IB * G * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int l = idx & 63, T = (idx >> 6) % G, ib = (idx >> 6) / G;
+        const int c = l & 31, h = l >> 5;
+        const int i = 32 * ib + c;
+        const int col = (d.mode & FRAG_PERMROWS) ? (16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)) : i;
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int kk = (d.mode & FRAG_FEATMAP) ? (16 * h + 4 * T + q) : (8 * T + 4 * h + q);
+            float x = 0.0f;
+            if (i < d.I && kk < d.K)
+                x = (d.mode & FRAG_TRANSPOSE) ? d.src[(size_t)kk * d.ld + col] : d.src[(size_t)col * d.ld + kk];
+            v[q] = x;
+        }
+        reinterpret_cast<float4*>(d.dst)[idx] = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// acc[nb] (+)= W[32nb.., :] * relu?(X)   for a 128-wide input held in x[4] (accumulator layout)
+__device__ __forceinline__ float4 frag_load(const float* packed, int ib, int G, int T, int lane) {
+    return reinterpret_cast<const float4*>(packed)[(size_t)(ib * G + T) * 64 + lane];
+}
+
+// acc (+)= W[row block ib] * relu?(X) for a 128-wide X held in x[4] (accumulator layout)
 template <bool RELU>
-__device__ __forceinline__ void layer128(const float* lds_w, int nb, int c, int h, const floatx16* x, floatx16& acc) {
+__device__ __forceinline__ void layer128(const float* packed, int ib, int lane, const floatx16* x, floatx16& acc) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int T = 0; T < 16; ++T) {
+        const float4 a4 = frag_load(packed, ib, 16, T, lane);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 a4 = *reinterpret_cast<const float4*>(lds_w + (32 * nb + c) * WSTRIDE + 32 * b + 8 * t + 4 * h);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float xv = x[b][4 * t + q];
-                if (RELU) xv = fmaxf(xv, 0.0f);
-                acc = MFMA(av[q], xv, acc);
-            }
+        for (int q = 0; q < 4; ++q) {
+            float xv = x[T >> 2][4 * (T & 3) + q];
+            if (RELU) xv = fmaxf(xv, 0.0f);
+            acc = MFMA(av[q], xv, acc);
         }
+    }
+}
+
+// all four 32-row blocks of a 128x128 layer at once: one B value feeds four independent accumulators
+template <bool RELU>
+__device__ __forceinline__ void layer128x4(const float* packed, int lane, const floatx16* x, floatx16* acc) {
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        float av[4][4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const float4 a4 = frag_load(packed, nb, 16, T, lane);
+            av[nb][0] = a4.x; av[nb][1] = a4.y; av[nb][2] = a4.z; av[nb][3] = a4.w;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float xv = x[T >> 2][4 * (T & 3) + q];
+            if (RELU) xv = fmaxf(xv, 0.0f);
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) acc[nb] = MFMA(av[nb][q], xv, acc[nb]);
+        }
+    }
 }
 
 __device__ __forceinline__ floatx16 bias_init(const float* __restrict__ bias, int nb, int h, int valid_rows) {
@@ -238,18 +283,16 @@ struct DeformFwdK {
     int n;
     PlaneSet ps;
     const float* aabb;
-    const float* w0; const float* b0;
-    const float* w1[5]; const float* b1[5]; const float* w2[5]; const float* b2[5];
-    const float* xyz; const float* in[5];     // in[0] = xyz ... in[4] = shs (residual inputs)
+    const float* pw0; const float* b0;              // packed first Linear
+    const float* pw1[5]; const float* b1[5]; const float* pw2[5]; const float* b2[5];
+    const float* xyz; const float* in[5];           // in[0] = xyz ... in[4] = shs (residual inputs)
     const float* time; float time_scalar;
     float* out[5];
     float* save_hidden;
 };
 
-// two workgroups per CU: one stages weights while the other issues MFMAs
 __global__ void __launch_bounds__(256, 2)
 deform_fwd_kernel(DeformFwdK a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int p = blockIdx.x * TILE_PTS + wave * 32 + c;
@@ -261,19 +304,17 @@ deform_fwd_kernel(DeformFwdK a) {
     level_features(a.ps, h, co, feat, nullptr);
 
     // hidden^T = W0 f^T + b0
-    stage_w0(lds, a.w0);
-    __syncthreads();
     floatx16 hid[4];
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) {
         hid[nb] = bias_init(a.b0, nb, h, DW);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 a4 = *reinterpret_cast<const float4*>(lds + (32 * nb + c) * W0STRIDE + 16 * h + 4 * t);
-            hid[nb] = MFMA(a4.x, feat[4 * t + 0], hid[nb]);
-            hid[nb] = MFMA(a4.y, feat[4 * t + 1], hid[nb]);
-            hid[nb] = MFMA(a4.z, feat[4 * t + 2], hid[nb]);
-            hid[nb] = MFMA(a4.w, feat[4 * t + 3], hid[nb]);
+        for (int T = 0; T < 4; ++T) {
+            const float4 a4 = frag_load(a.pw0, nb, 4, T, lane);
+            hid[nb] = MFMA(a4.x, feat[4 * T + 0], hid[nb]);
+            hid[nb] = MFMA(a4.y, feat[4 * T + 1], hid[nb]);
+            hid[nb] = MFMA(a4.z, feat[4 * T + 2], hid[nb]);
+            hid[nb] = MFMA(a4.w, feat[4 * T + 3], hid[nb]);
         }
     }
     if (a.save_hidden && pvalid) {
@@ -287,25 +328,17 @@ deform_fwd_kernel(DeformFwdK a) {
 
     for (int head = 0; head < 5; ++head) {
         const int k = head_dim(head);
-        const float* w1 = sel5(a.w1, head); const float* b1 = sel5(a.b1, head);
-        const float* w2 = sel5(a.w2, head); const float* b2 = sel5(a.b2, head);
+        const float* pw1 = sel5(a.pw1, head); const float* b1 = sel5(a.b1, head);
+        const float* pw2 = sel5(a.pw2, head); const float* b2 = sel5(a.b2, head);
         const float* in = sel5(a.in, head); float* out = sel5(a.out, head);
-        __syncthreads();
-        stage_w128(lds, w1, DW, DW);
-        __syncthreads();
         floatx16 h1[4];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            h1[nb] = bias_init(b1, nb, h, DW);
-            layer128<true>(lds, nb, c, h, hid, h1[nb]);
-        }
-        __syncthreads();
+        for (int nb = 0; nb < 4; ++nb) h1[nb] = bias_init(b1, nb, h, DW);
+        layer128x4<true>(pw1, lane, hid, h1);
         const int nblk = (k + 31) >> 5;
-        stage_w128(lds, w2, k, 32 * nblk);
-        __syncthreads();
         for (int ob = 0; ob < nblk; ++ob) {
             floatx16 o = bias_init(b2, ob, h, k);
-            layer128<true>(lds, ob, c, h, h1, o);
+            layer128<true>(pw2, ob, lane, h1, o);
             if (pvalid) {
                 if ((k & 3) == 0) {
 #pragma unroll
@@ -326,6 +359,96 @@ deform_fwd_kernel(DeformFwdK a) {
                 }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wide layers (used by the backward): one wave owns 64 points (two column
+// blocks) and the whole 512-register file.  Every weight fragment fetched from
+// L2 feeds two MFMAs per accumulator row block, and the next K group's
+// fragments are requested one full group (32 MFMAs) ahead.
+// ---------------------------------------------------------------------------
+#define NCB 2
+template <bool RELU>
+__device__ __forceinline__ void wide_layer128x4(const float* packed, int lane, const floatx16 (*x)[4],
+                                                floatx16 (*acc)[4]) {
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) cur[nb] = frag_load(packed, nb, 16, 0, lane);
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        if (T + 1 < 16) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) nxt[nb] = frag_load(packed, nb, 16, T + 1, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                float xv = x[cb][T >> 2][4 * (T & 3) + q];
+                if (RELU) xv = fmaxf(xv, 0.0f);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const float av = q == 0 ? cur[nb].x : q == 1 ? cur[nb].y : q == 2 ? cur[nb].z : cur[nb].w;
+                    acc[cb][nb] = MFMA(av, xv, acc[cb][nb]);
+                }
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) cur[nb] = nxt[nb];
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance at one K group (bounds live registers)
+    }
+}
+
+// same, with the B operand (relu of a [128 features][64 points] tile) read from this wave's LDS tile
+__device__ __forceinline__ void wide_layer128x4_ldsb(const float* packed, int lane, const float* tile,
+                                                     floatx16 (*acc)[4]) {
+    const int c = lane & 31, h = lane >> 5;
+    float4 cur[4], nxt[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) cur[nb] = frag_load(packed, nb, 16, 0, lane);
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        if (T + 1 < 16) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) nxt[nb] = frag_load(packed, nb, 16, T + 1, lane);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const float xv = fmaxf(tile[(8 * T + 4 * h + q) * 64 + 32 * cb + c], 0.0f);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const float av = q == 0 ? cur[nb].x : q == 1 ? cur[nb].y : q == 2 ? cur[nb].z : cur[nb].w;
+                    acc[cb][nb] = MFMA(av, xv, acc[cb][nb]);
+                }
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) cur[nb] = nxt[nb];
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance at one K group (bounds live registers)
+    }
+}
+
+template <bool RELU>
+__device__ __forceinline__ void wide_layer128(const float* packed, int ib, int lane, const floatx16 (*x)[4],
+                                              floatx16* acc) {
+    float4 cur = frag_load(packed, ib, 16, 0, lane), nxt = cur;
+#pragma unroll
+    for (int T = 0; T < 16; ++T) {
+        if (T + 1 < 16) nxt = frag_load(packed, ib, 16, T + 1, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float av = q == 0 ? cur.x : q == 1 ? cur.y : q == 2 ? cur.z : cur.w;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                float xv = x[cb][T >> 2][4 * (T & 3) + q];
+                if (RELU) xv = fmaxf(xv, 0.0f);
+                acc[cb] = MFMA(av, xv, acc[cb]);
+            }
+        }
+        cur = nxt;
     }
 }
 
@@ -356,9 +479,28 @@ static size_t total_plane_floats(const fdgs_deform_params* p) {
     return t;
 }
 
+static const int h_head_dim[5] = {3, 3, 4, 1, 48};
+
+static size_t fwd_packed_floats() {
+    size_t t = frag_floats(DW, 32);
+    for (int h = 0; h < 5; ++h) t += frag_floats(DW, DW) + frag_floats(h_head_dim[h], DW);
+    return t;
+}
+static size_t bwd_packed_floats() {
+    size_t t = frag_floats(32, DW);
+    for (int h = 0; h < 5; ++h) t += 2 * frag_floats(DW, DW) + frag_floats(DW, h_head_dim[h]);
+    return t;
+}
+
 extern "C" size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p) {
     if (!p || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS) return 0;
-    return total_plane_floats(p) * sizeof(float);
+    return (total_plane_floats(p) + fwd_packed_floats()) * sizeof(float);
+}
+
+static int launch_pack(const FragTable& t, hipStream_t s) {
+    hipLaunchKernelGGL(pack_fragments_kernel, dim3(16, t.n), dim3(256), 0, s, t);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
 }
 
 // fills ps with the channel-last plane addresses inside ws and (unless the caller
@@ -396,10 +538,26 @@ extern "C" int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     DeformFwdK k;
     k.n = a->num_points;
-    int rc = make_plane_set(&a->p, (float*)a->workspace, &k.ps, true, s);
+    float* ws = (float*)a->workspace;
+    int rc = make_plane_set(&a->p, ws, &k.ps, true, s);
     if (rc != FDGS_OK) return rc;
-    k.aabb = a->p.aabb; k.w0 = a->p.w0; k.b0 = a->p.b0;
-    for (int h = 0; h < 5; ++h) { k.w1[h] = a->p.w1[h]; k.b1[h] = a->p.b1[h]; k.w2[h] = a->p.w2[h]; k.b2[h] = a->p.b2[h]; }
+    {   // weight fragments behind the plane copies
+        float* pk = ws + total_plane_floats(&a->p);
+        FragTable t;
+        t.n = 0;
+        t.d[t.n++] = FragDesc{a->p.w0, pk, DW, 32, 32, FRAG_FEATMAP};
+        k.pw0 = pk; pk += frag_floats(DW, 32);
+        for (int h = 0; h < 5; ++h) {
+            t.d[t.n++] = FragDesc{a->p.w1[h], pk, DW, DW, DW, 0};
+            k.pw1[h] = pk; pk += frag_floats(DW, DW);
+            t.d[t.n++] = FragDesc{a->p.w2[h], pk, h_head_dim[h], DW, DW, 0};
+            k.pw2[h] = pk; pk += frag_floats(h_head_dim[h], DW);
+        }
+        rc = launch_pack(t, s);
+        if (rc != FDGS_OK) return rc;
+    }
+    k.aabb = a->p.aabb; k.b0 = a->p.b0;
+    for (int h = 0; h < 5; ++h) { k.b1[h] = a->p.b1[h]; k.b2[h] = a->p.b2[h]; }
     k.xyz = a->xyz;
     k.in[0] = a->xyz; k.in[1] = a->scales; k.in[2] = a->rotations; k.in[3] = a->opacity; k.in[4] = a->shs;
     k.out[0] = a->out_xyz; k.out[1] = a->out_scales; k.out[2] = a->out_rotations; k.out[3] = a->out_opacity;
@@ -407,15 +565,10 @@ extern "C" int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream) {
     k.time = a->time; k.time_scalar = a->time_scalar;
     k.save_hidden = a->save_hidden;
     const int blocks = (a->num_points + TILE_PTS - 1) / TILE_PTS;
-    const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    if (hipFuncSetAttribute((const void*)deform_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes) != hipSuccess)
-        return FDGS_ELAUNCH;
-    hipLaunchKernelGGL(deform_fwd_kernel, dim3(blocks), dim3(256), lds_bytes, s, k);
+    hipLaunchKernelGGL(deform_fwd_kernel, dim3(blocks), dim3(256), 0, s, k);
     FDGS_CHECK_LAUNCH();
     return FDGS_OK;
 }
-
 
 // ===========================================================================
 // Backward
@@ -431,144 +584,139 @@ extern "C" int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream) {
 // two 128-byte row segments per wave instruction.
 struct DeformBwdK {
     int n;
-    const float* w0;
-    const float* w1[5]; const float* b1[5]; const float* w2[5];
+    const float* pw1[5]; const float* b1[5];    // packed W1 (recompute of h1)
+    const float* pw2t[5];                       // packed W2^T : A[kk][o]
+    const float* pw1t[5];                       // packed W1^T : A[kk][n]
+    const float* pw0t;                          // packed W0^T with permuted rows
     const float* hidden;
     const float* g[5];                   // output cotangents
     float* ws_a1; float* ws_dh1; float* ws_dhid; float* ws_df;
 };
 
-// one wave per SIMD: the backward keeps three 64-register accumulator tiles live (no spills at 512 registers)
-__global__ void __launch_bounds__(256, 1)
+// Pass 1: one wave per workgroup, 64 points per wave (two column blocks); hidden^T of the wave's points
+// lives in LDS (B operand of the h1 recompute), dacc and the h1/dh1 tile in registers.
+__global__ void __launch_bounds__(64, 1)
 deform_bwd_points_kernel(DeformBwdK a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float tile[DW * 64];          // hidden^T of this wave's 64 points: [feature][point], 32 KiB
+    const int lane = threadIdx.x & 63;
     const int c = lane & 31, h = lane >> 5;
-    const int p = blockIdx.x * TILE_PTS + wave * 32 + c;
-    const bool pvalid = p < a.n;
-    const int pc = pvalid ? p : a.n - 1;
-
-    // hidden (saved by the forward) in accumulator layout
-    floatx16 hid[4];
+    int p[NCB]; bool pvalid[NCB];
+    floatx16 dacc[NCB][4];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
+    for (int cb = 0; cb < NCB; ++cb) {
+        p[cb] = blockIdx.x * (32 * NCB) + 32 * cb + c;
+        pvalid[cb] = p[cb] < a.n;
+        const int pc = pvalid[cb] ? p[cb] : a.n - 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(a.hidden + (size_t)pc * DW + 32 * nb + 8 * q + 4 * h);
-            hid[nb][4 * q] = v.x; hid[nb][4 * q + 1] = v.y; hid[nb][4 * q + 2] = v.z; hid[nb][4 * q + 3] = v.w;
+        for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = 32 * nb + 8 * q + 4 * h;
+                const float4 v = *reinterpret_cast<const float4*>(a.hidden + (size_t)pc * DW + f);
+                tile[(f + 0) * 64 + 32 * cb + c] = v.x; tile[(f + 1) * 64 + 32 * cb + c] = v.y;
+                tile[(f + 2) * 64 + 32 * cb + c] = v.z; tile[(f + 3) * 64 + 32 * cb + c] = v.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[cb][nb][r] = 0.0f;
         }
-    floatx16 dacc[4];
-#pragma unroll
-    for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dacc[nb][r] = 0.0f;
-
+    }
     for (int head = 0; head < 5; ++head) {
         const int k = head_dim(head);
-        const float* w1 = sel5(a.w1, head); const float* b1 = sel5(a.b1, head);
-        const float* w2 = sel5(a.w2, head); const float* g = sel5(a.g, head);
-        __syncthreads();
-        stage_w128(lds, w1, DW, DW);
-        __syncthreads();
-        // h1 = W1 relu(hidden) + b1 ; keep only the sign mask, store a1 = relu(h1)
-        unsigned long long pos_mask = 0ull;       // bit (16*nb + r) : h1[nb][r] > 0
+        const float* pw1 = sel5(a.pw1, head); const float* b1 = sel5(a.b1, head);
+        const float* pw2t = sel5(a.pw2t, head); const float* pw1t = sel5(a.pw1t, head);
+        const float* g = sel5(a.g, head);
+        floatx16 t[NCB][4];      // h1, then dh1
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            floatx16 h1 = bias_init(b1, nb, h, DW);
-            layer128<true>(lds, nb, c, h, hid, h1);
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (h1[r] > 0.0f) pos_mask |= (1ull << (16 * nb + r));
-            if (pvalid) {
+            for (int nb = 0; nb < 4; ++nb) t[cb][nb] = bias_init(b1, nb, h, DW);
+        wide_layer128x4_ldsb(pw1, lane, tile, t);
+        unsigned long long pos_mask[NCB];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(a.ws_a1 + (size_t)p * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
-                        make_float4(fmaxf(h1[4 * q], 0.f), fmaxf(h1[4 * q + 1], 0.f), fmaxf(h1[4 * q + 2], 0.f),
-                                    fmaxf(h1[4 * q + 3], 0.f));
-            }
-        }
-        // da1^T[kk][p] = sum_o W2[o][kk] g[p][o]  (A = W2 read from global: lanes run along kk, coalesced)
-        floatx16 dh1[4];
-        const int osteps = (k + 1) >> 1;
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dh1[nb][r] = 0.0f;
-        }
-        for (int s = 0; s < osteps; ++s) {
-            const int o = 2 * s + h;
-            const bool ov = o < k;
-            const float gv = (ov && pvalid) ? g[(size_t)p * k + o] : 0.0f;
+        for (int cb = 0; cb < NCB; ++cb) {
+            pos_mask[cb] = 0ull;
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb) {
-                const float av = ov ? w2[(size_t)o * DW + 32 * nb + c] : 0.0f;
-                dh1[nb] = MFMA(av, gv, dh1[nb]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t[cb][nb][r] > 0.0f) pos_mask[cb] |= (1ull << (16 * nb + r));
+                if (pvalid[cb]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(a.ws_a1 + (size_t)p[cb] * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
+                            make_float4(fmaxf(t[cb][nb][4 * q], 0.f), fmaxf(t[cb][nb][4 * q + 1], 0.f),
+                                        fmaxf(t[cb][nb][4 * q + 2], 0.f), fmaxf(t[cb][nb][4 * q + 3], 0.f));
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[cb][nb][r] = 0.0f;
             }
         }
-        // dh1 = da1 * (h1 > 0); store for the weight gradients
+        const int G2 = (k + 7) >> 3;
+        for (int T = 0; T < G2; ++T) {
+            float gv[NCB][4];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = 8 * T + 4 * h + q;
+                    gv[cb][q] = (o < k && pvalid[cb]) ? g[(size_t)p[cb] * k + o] : 0.0f;
+                }
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                const float4 a4 = frag_load(pw2t, nb, G2, T, lane);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    t[cb][nb] = MFMA(a4.x, gv[cb][0], t[cb][nb]);
+                    t[cb][nb] = MFMA(a4.y, gv[cb][1], t[cb][nb]);
+                    t[cb][nb] = MFMA(a4.z, gv[cb][2], t[cb][nb]);
+                    t[cb][nb] = MFMA(a4.w, gv[cb][3], t[cb][nb]);
+                }
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!((pos_mask[cb] >> (16 * nb + r)) & 1ull)) t[cb][nb][r] = 0.0f;
+                if (pvalid[cb]) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(a.ws_dh1 + (size_t)p[cb] * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
+                            make_float4(t[cb][nb][4 * q], t[cb][nb][4 * q + 1], t[cb][nb][4 * q + 2], t[cb][nb][4 * q + 3]);
+                }
+            }
+        wide_layer128x4<false>(pw1t, lane, t, dacc);
+    }
+    floatx16 df[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (!((pos_mask >> (16 * nb + r)) & 1ull)) dh1[nb][r] = 0.0f;
-            if (pvalid) {
+                if (!(tile[(32 * nb + drow(r, h)) * 64 + 32 * cb + c] > 0.0f)) dacc[cb][nb][r] = 0.0f;
+            if (pvalid[cb]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(a.ws_dh1 + (size_t)p * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
-                        make_float4(dh1[nb][4 * q], dh1[nb][4 * q + 1], dh1[nb][4 * q + 2], dh1[nb][4 * q + 3]);
+                    *reinterpret_cast<float4*>(a.ws_dhid + (size_t)p[cb] * DW + 32 * nb + 8 * q + 4 * h) =
+                        make_float4(dacc[cb][nb][4 * q], dacc[cb][nb][4 * q + 1], dacc[cb][nb][4 * q + 2],
+                                    dacc[cb][nb][4 * q + 3]);
             }
         }
-        // dacc^T[kk][p] += sum_n W1[n][kk] dh1^T[n][p]   (A[i=kk][n] = W1[n][kk] from the LDS image)
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float av = lds[(32 * b + drow(r, h)) * WSTRIDE + 32 * kb + c];
-                    dacc[kb] = MFMA(av, dh1[b][r], dacc[kb]);
-                }
+        for (int r = 0; r < 16; ++r) df[cb][r] = 0.0f;
     }
-
-    // dhidden = dacc * (hidden > 0)
+    wide_layer128<false>(a.pw0t, 0, lane, dacc, df);
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (!(hid[nb][r] > 0.0f)) dacc[nb][r] = 0.0f;
-        if (pvalid) {
+    for (int cb = 0; cb < NCB; ++cb)
+        if (pvalid[cb]) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<float4*>(a.ws_dhid + (size_t)p * DW + 32 * nb + 8 * q + 4 * h) =
-                    make_float4(dacc[nb][4 * q], dacc[nb][4 * q + 1], dacc[nb][4 * q + 2], dacc[nb][4 * q + 3]);
+                *reinterpret_cast<float4*>(a.ws_df + (size_t)p[cb] * 32 + 16 * h + 4 * q) =
+                    make_float4(df[cb][4 * q], df[cb][4 * q + 1], df[cb][4 * q + 2], df[cb][4 * q + 3]);
         }
-    }
-
-    // df^T = W0^T dhidden^T with output row i carrying feature perm(i) = 16*((i>>2)&1) + 4*(i>>3) + (i&3),
-    // so that register r of lane (c,h) is dL/dfeature[16h + r]: the level this lane interpolates.
-    __syncthreads();
-    stage_w0(lds, a.w0);
-    __syncthreads();
-    floatx16 df;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) df[r] = 0.0f;
-    {
-        const int pcol = 16 * ((c >> 2) & 1) + 4 * (c >> 3) + (c & 3);
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float av = lds[(32 * b + drow(r, h)) * W0STRIDE + pcol];
-                df = MFMA(av, dacc[b][r], df);
-            }
-    }
-
-    if (pvalid) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            *reinterpret_cast<float4*>(a.ws_df + (size_t)p * 32 + 16 * h + 4 * q) =
-                make_float4(df[4 * q], df[4 * q + 1], df[4 * q + 2], df[4 * q + 3]);
-    }
 }
 
 // ---------------------------------------------------------------------------
@@ -800,11 +948,20 @@ deform_wgrad_kernel(WGradK a) {
     if (d.db && mv) atomicAdd(d.db + m0 + c, bsum);
 }
 
+// points per backward chunk: bounds the a1 / dh1 workspace (5 KiB per point) for very large point counts;
+// smaller chunks measured slower (the chip drains between the launches)
+static int bwd_chunk_points(int n) {
+    int c = 524288;
+    if (c > n) c = n;
+    return c < 1 ? 1 : c;
+}
+
 extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points) {
     if (!p || num_points < 0 || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS) return 0;
     const size_t pf = total_plane_floats(p);
-    const size_t per_point = 640 + 640 + DW + 32 + 32;
-    return (2 * pf + per_point * (size_t)num_points) * sizeof(float);
+    const size_t per_point = DW + 32 + 32;
+    return (2 * pf + bwd_packed_floats() + per_point * (size_t)num_points +
+            (size_t)1280 * bwd_chunk_points(num_points)) * sizeof(float);
 }
 
 extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
@@ -820,9 +977,11 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     float* ws = (float*)a->workspace;
     float* planes_cl = ws;
     float* grads_cl = ws + pf;
-    float* ws_a1 = grads_cl + pf;
-    float* ws_dh1 = ws_a1 + (size_t)640 * n;
-    float* ws_dhid = ws_dh1 + (size_t)640 * n;
+    float* ws_packed = grads_cl + pf;
+    float* ws_a1 = ws_packed + bwd_packed_floats();
+    const size_t chunk_cap = (size_t)bwd_chunk_points(n);
+    float* ws_dh1 = ws_a1 + (size_t)640 * chunk_cap;
+    float* ws_dhid = ws_dh1 + (size_t)640 * chunk_cap;
     float* ws_feat = ws_dhid + (size_t)DW * n;
 
     float* ws_df = ws_feat + (size_t)32 * n;
@@ -844,18 +1003,63 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     }
     DeformBwdK k;
     k.n = n;
-    k.w0 = a->p.w0;
-    for (int h = 0; h < 5; ++h) { k.w1[h] = a->p.w1[h]; k.b1[h] = a->p.b1[h]; k.w2[h] = a->p.w2[h]; }
+    {
+        float* pk = ws_packed;
+        FragTable t;
+        t.n = 0;
+        t.d[t.n++] = FragDesc{a->p.w0, pk, 32, DW, 32, FRAG_TRANSPOSE | FRAG_PERMROWS};
+        k.pw0t = pk; pk += frag_floats(32, DW);
+        for (int h = 0; h < 5; ++h) {
+            t.d[t.n++] = FragDesc{a->p.w1[h], pk, DW, DW, DW, 0};
+            k.pw1[h] = pk; pk += frag_floats(DW, DW);
+            t.d[t.n++] = FragDesc{a->p.w1[h], pk, DW, DW, DW, FRAG_TRANSPOSE};
+            k.pw1t[h] = pk; pk += frag_floats(DW, DW);
+            t.d[t.n++] = FragDesc{a->p.w2[h], pk, DW, h_head_dim[h], DW, FRAG_TRANSPOSE};
+            k.pw2t[h] = pk; pk += frag_floats(DW, h_head_dim[h]);
+        }
+        rc = launch_pack(t, s);
+        if (rc != FDGS_OK) return rc;
+    }
+    for (int h = 0; h < 5; ++h) k.b1[h] = a->p.b1[h];
     k.hidden = a->hidden;
     k.g[0] = a->g_xyz; k.g[1] = a->g_scales; k.g[2] = a->g_rotations; k.g[3] = a->g_opacity; k.g[4] = a->g_shs;
     k.ws_a1 = ws_a1; k.ws_dh1 = ws_dh1; k.ws_dhid = ws_dhid; k.ws_df = ws_df;
-    const int blocks = (n + TILE_PTS - 1) / TILE_PTS;
-    const size_t lds_bytes = LDS_FLOATS * sizeof(float);
-    if (hipFuncSetAttribute((const void*)deform_bwd_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds_bytes) != hipSuccess)
-        return FDGS_ELAUNCH;
-    hipLaunchKernelGGL(deform_bwd_points_kernel, dim3(blocks), dim3(256), lds_bytes, s, k);
-    FDGS_CHECK_LAUNCH();
+    // Points are processed in chunks: each chunk's a1 / dh1 operands are consumed by the weight-gradient
+    // products right after they are produced and the workspace holds one chunk only.
+    static const int kdim[5] = {3, 3, 4, 1, 48};
+    const float* gs[5] = {a->g_xyz, a->g_scales, a->g_rotations, a->g_opacity, a->g_shs};
+    const int chunk_pts = bwd_chunk_points(n);
+    for (int c0 = 0; c0 < n; c0 += chunk_pts) {
+        const int cn = (n - c0) < chunk_pts ? (n - c0) : chunk_pts;
+        DeformBwdK kc = k;
+        kc.n = cn;
+        kc.hidden = a->hidden + (size_t)c0 * DW;
+        for (int h = 0; h < 5; ++h) kc.g[h] = gs[h] + (size_t)c0 * kdim[h];
+        kc.ws_dhid = ws_dhid + (size_t)c0 * DW;
+        kc.ws_df = ws_df + (size_t)c0 * 32;
+        hipLaunchKernelGGL(deform_bwd_points_kernel, dim3((cn + 32 * NCB - 1) / (32 * NCB)), dim3(64), 0, s, kc);
+        FDGS_CHECK_LAUNCH();
+        WGradK w;
+        w.n = cn;
+        w.chunk = 1024;
+        int nd = 0;
+        for (int h = 0; h < 5; ++h) {           // dW1_h[nn][kk] = sum_p dh1[p][nn] * relu(hidden)[p][kk]
+            WGradDesc& d = w.d[nd++];
+            d.X = ws_dh1 + h * DW; d.ldx = 640; d.M = DW;
+            d.Y = kc.hidden; d.ldy = DW; d.NN = DW; d.relu_y = 1;
+            d.C = a->dp.w1[h]; d.ldc = DW; d.db = a->dp.b1[h];
+        }
+        for (int h = 0; h < 5; ++h) {           // dW2_h[o][kk] = sum_p g[p][o] * a1_h[p][kk]
+            WGradDesc& d = w.d[nd++];
+            d.X = kc.g[h]; d.ldx = kdim[h]; d.M = kdim[h];
+            d.Y = ws_a1 + h * DW; d.ldy = 640; d.NN = DW; d.relu_y = 0;
+            d.C = a->dp.w2[h]; d.ldc = DW; d.db = a->dp.b2[h];
+        }
+        w.d[nd].C = nullptr; w.d[nd].X = nullptr; w.d[nd].Y = nullptr; w.d[nd].db = nullptr;
+        w.d[nd].M = 0; w.d[nd].NN = 0; w.d[nd].ldx = w.d[nd].ldy = w.d[nd].ldc = 0; w.d[nd].relu_y = 0;
+        hipLaunchKernelGGL(deform_wgrad_kernel, dim3((cn + w.chunk - 1) / w.chunk, WG_MAX - 1), dim3(256), 0, s, w);
+        FDGS_CHECK_LAUNCH();
+    }
 
     // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
     hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
@@ -878,36 +1082,21 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)hb), dim3(256), hex_lds_bytes, s, hk, hex_lds_floats);
         FDGS_CHECK_LAUNCH();
     }
-
-    // weight gradients
-    static const int kdim[5] = {3, 3, 4, 1, 48};
-    WGradK w;
-    w.n = n;
-    w.chunk = 1024;
-    int nd = 0;
-    for (int h = 0; h < 5; ++h) {           // dW1_h[nn][kk] = sum_p dh1[p][nn] * relu(hidden)[p][kk]
-        WGradDesc& d = w.d[nd++];
-        d.X = ws_dh1 + h * DW; d.ldx = 640; d.M = DW;
-        d.Y = a->hidden; d.ldy = DW; d.NN = DW; d.relu_y = 1;
-        d.C = a->dp.w1[h]; d.ldc = DW; d.db = a->dp.b1[h];
-        if (!d.C) d.C = nullptr;
-    }
-    const float* gs[5] = {a->g_xyz, a->g_scales, a->g_rotations, a->g_opacity, a->g_shs};
-    for (int h = 0; h < 5; ++h) {           // dW2_h[o][kk] = sum_p g[p][o] * a1_h[p][kk]
-        WGradDesc& d = w.d[nd++];
-        d.X = gs[h]; d.ldx = kdim[h]; d.M = kdim[h];
-        d.Y = ws_a1 + h * DW; d.ldy = 640; d.NN = DW; d.relu_y = 0;
-        d.C = a->dp.w2[h]; d.ldc = DW; d.db = a->dp.b2[h];
-    }
-    {                                       // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f]
-        WGradDesc& d = w.d[nd++];
+    {                                           // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f]
+        WGradK w;
+        w.n = n;
+        w.chunk = 1024;
+        for (int i = 0; i < WG_MAX; ++i) {
+            w.d[i].C = nullptr; w.d[i].X = nullptr; w.d[i].Y = nullptr; w.d[i].db = nullptr;
+            w.d[i].M = 0; w.d[i].NN = 0; w.d[i].ldx = w.d[i].ldy = w.d[i].ldc = 0; w.d[i].relu_y = 0;
+        }
+        WGradDesc& d = w.d[0];
         d.X = ws_dhid; d.ldx = DW; d.M = DW;
         d.Y = ws_feat; d.ldy = 32; d.NN = 32; d.relu_y = 0;
         d.C = a->dp.w0; d.ldc = 32; d.db = a->dp.b0;
+        hipLaunchKernelGGL(deform_wgrad_kernel, dim3((n + w.chunk - 1) / w.chunk, 1), dim3(256), 0, s, w);
+        FDGS_CHECK_LAUNCH();
     }
-    const int chunks = (n + w.chunk - 1) / w.chunk;
-    hipLaunchKernelGGL(deform_wgrad_kernel, dim3(chunks, WG_MAX), dim3(256), 0, s, w);
-    FDGS_CHECK_LAUNCH();
 
     // plane gradients back to the parameter layout [16][H][W] (one launch, += into the caller's buffers)
     {
