@@ -199,8 +199,8 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
             float v_mx = 0.f, v_my = 0.f, v_A = 0.f, v_B = 0.f, v_C = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
             if (contrib) {
                 const float cr = bcast(g1.z, j), cg = bcast(g1.w, j), cb = bcast(g2.x, j);
-                const float one_m = 1.0f - alpha;
-                T = T / one_m;
+                const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1 ulp; alpha <= 0.99
+                T = T * inv_one_m;
                 const float w = alpha * T;
                 acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r;
                 acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g;
@@ -210,7 +210,7 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
                 v_r = w * dLr; v_g = w * dLg; v_b = w * dLb;
                 dL_dalpha *= T;
                 last_alpha = alpha;
-                dL_dalpha += (-T_final / one_m) * bg_dot;
+                dL_dalpha += (-T_final * inv_one_m) * bg_dot;
                 const float dL_dG = o * dL_dalpha;
                 const float gdx = G * dx, gdy = G * dy;
                 v_mx = dL_dG * (-gdx * A - gdy * B);

@@ -174,7 +174,12 @@ class _DeformFunction(torch.autograd.Function):
         g_sc = c(g_sc, torch.empty(N, 3, device=dev)); g_ro = c(g_ro, torch.empty(N, 4, device=dev))
         g_op = c(g_op, torch.empty(N, 1, device=dev)); g_sh = c(g_sh, torch.empty(N, 16, 3, device=dev))
         params = _trainable(net)
-        grads = {id(p): torch.zeros_like(p, memory_format=torch.contiguous_format) for p in params}
+        # one zero-filled flat buffer, viewed per parameter (the library accumulates into it)
+        flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
+        grads, off = {}, 0
+        for p in params:
+            grads[id(p)] = flat[off:off + p.numel()].view(p.shape)
+            off += p.numel()
         P = _fill_params(net)
         G = _fill_params(net, grads)
         d_xyz = torch.empty_like(xyz_c)
