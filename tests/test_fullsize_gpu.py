@@ -1,0 +1,118 @@
+"""Full-size GPU checks at BASELINE.json's sizes (300k Gaussians at 1352x1014; 2M-Gaussian stress):
+integer stages bit-exact against the oracle on the whole scene, image / n_contrib and the backward pass
+against the oracle on a sample of tiles (the loss is restricted to those tiles, so the per-Gaussian
+gradients are comparable), plus size-independent properties (sortedness, range partition, linearity)."""
+import math
+
+import pytest
+import torch
+
+from fdgs import scene_synth as ss
+from oracle import raster_ref as rr
+
+pytestmark = pytest.mark.gpu
+W, H = 1352, 1014
+
+
+def _scene(n, scale_mult):
+    cam = ss.make_cameras(21, W, H)[7]
+    g = ss.GaussianParams(n, scale_mult=scale_mult, requires_grad=False)
+    ins = dict(means3D=g._xyz, shs=g.get_features.contiguous(), opacities=torch.sigmoid(g._opacity),
+               scales=torch.exp(g._scaling), rotations=torch.nn.functional.normalize(g._rotation))
+    S = rr.Settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.ones(3), 1.0,
+                    cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center)
+    return ins, S
+
+
+def _gpu_settings(S, dev):
+    from fdgs.rasterizer import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.bg.to(dev),
+                                         S.scale_modifier, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.sh_degree,
+                                         S.campos.to(dev), False, False)
+
+
+def _check_structure(st, R, n_tiles):
+    keys = st.keys_sorted[:R]
+    assert bool((keys[1:] >= keys[:-1]).all()), "keys not sorted"
+    ranges = st.ranges.long()
+    lens = ranges[:, 1] - ranges[:, 0]
+    assert int(lens.sum()) == R and bool((lens >= 0).all())
+    nz = torch.nonzero(lens)[:, 0]
+    tile_of = (keys >> 32)
+    assert bool((tile_of[ranges[nz, 0]] == nz).all()) and bool((tile_of[ranges[nz, 1] - 1] == nz).all())
+    assert int(tile_of.max()) < n_tiles
+
+
+@pytest.mark.parametrize("n,scale_mult", [(300000, 1.0), (2000000, 0.6)])
+def test_integer_stages_bit_exact_full_scene(n, scale_mult):
+    from fdgs import rasterizer as fr
+    dev = torch.device("cuda:0")
+    ins, S = _scene(n, scale_mult)
+    Sd = _gpu_settings(S, dev)
+    st = fr.rasterize_forward(ins["means3D"].to(dev), ins["shs"].to(dev), ins["opacities"].reshape(-1).to(dev),
+                              ins["scales"].to(dev), ins["rotations"].to(dev), Sd, keep_keys=True)
+    torch.cuda.synchronize()
+    pre = rr.preprocess(ins["means3D"], ins["scales"], ins["rotations"], ins["opacities"], ins["shs"], S)
+    keys, vals, offsets = rr.build_keys(pre, S)
+    skeys, svals = rr.sort_keys(keys, vals)
+    gx, gy = rr.tile_grid(S)
+    ranges = rr.tile_ranges(skeys, gx * gy)
+    R = keys.numel()
+    assert st.num_rendered == R
+    assert torch.equal(st.radii.cpu(), pre["radii"])
+    assert torch.equal(st.point_offsets.cpu(), offsets)
+    assert torch.equal(st.keys_sorted[:R].cpu(), skeys)
+    assert torch.equal(st.vals_sorted[:R].cpu(), svals)
+    assert torch.equal(st.ranges.cpu(), ranges)
+    _check_structure(st, R, gx * gy)
+    assert torch.isfinite(st.color).all() and float(st.final_T.min()) >= 0.0 and float(st.final_T.max()) <= 1.0
+    assert int((st.n_contrib.cpu().long().reshape(-1) > 0).sum()) > 0
+
+
+def test_sampled_tiles_forward_backward_300k():
+    from fdgs.rasterizer import GaussianRasterizer
+    dev = torch.device("cuda:0")
+    ins, S = _scene(300000, 1.0)
+    gx, gy = rr.tile_grid(S)
+    tiles = list(range(17, gx * gy, 131))           # 42 tiles spread over the image
+    mask = torch.zeros(gy * 16, gx * 16, dtype=torch.bool)
+    for t in tiles:
+        ty, tx = divmod(t, gx)
+        mask[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    mask = mask[:H, :W]
+    gout = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)) * mask
+
+    # oracle: blends only the sampled tiles
+    cin = {k: v.clone().requires_grad_(True) for k, v in ins.items()}
+    m2 = torch.zeros(300000, 3, requires_grad=True)
+    color, radii, depth, aux = rr.rasterize(cin["means3D"], m2, cin["shs"], cin["opacities"], cin["scales"],
+                                            cin["rotations"], S, tiles=tiles, return_aux=True)
+    (color * gout).sum().backward()
+
+    gin = {k: v.to(dev).requires_grad_(True) for k, v in ins.items()}
+    m2d = torch.zeros(300000, 3, device=dev, requires_grad=True)
+    img, rad, dep = GaussianRasterizer(_gpu_settings(S, dev))(
+        means3D=gin["means3D"], means2D=m2d, shs=gin["shs"], colors_precomp=None, opacities=gin["opacities"],
+        scales=gin["scales"], rotations=gin["rotations"], cov3D_precomp=None)
+    (img * gout.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    err = ((img.detach().cpu() - color).abs() * mask).max()
+    assert float(err) <= 1e-5, f"image on sampled tiles differs by {float(err)}"
+    derr = ((dep.detach().cpu() - depth).abs() * mask).max()
+    assert float(derr) <= 1e-4
+    for k in gin:
+        ref, got = cin[k].grad, gin[k].grad.cpu()
+        rel = float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+        assert rel <= 1e-4, f"{k}: {rel:.2e}"
+    rel = float((m2d.grad.cpu() - m2.grad).abs().max() / (m2.grad.abs().max() + 1e-30))
+    assert rel <= 1e-4
+
+    # linearity of the backward pass in the output cotangent (size-independent property)
+    g2 = {k: v.to(dev).requires_grad_(True) for k, v in ins.items()}
+    img2, _, _ = GaussianRasterizer(_gpu_settings(S, dev))(
+        means3D=g2["means3D"], means2D=torch.zeros(300000, 3, device=dev), shs=g2["shs"], colors_precomp=None,
+        opacities=g2["opacities"], scales=g2["scales"], rotations=g2["rotations"], cov3D_precomp=None)
+    (img2 * (2.0 * gout.to(dev))).sum().backward()
+    for k in gin:
+        a, b = 2.0 * gin[k].grad, g2[k].grad
+        assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 1e-5, k
