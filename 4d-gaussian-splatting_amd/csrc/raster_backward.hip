@@ -16,11 +16,15 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
 
     float dmean[3] = {0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dm2x = 0.f, dm2y = 0.f;
-    float* dsh = a.dL_dshs + (size_t)i * 48;
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcolor[3] = {0.f, 0.f, 0.f};
+    const bool use_sh = a.colors_precomp == nullptr, use_cov = a.cov3D_precomp != nullptr;
+    float* dsh = use_sh ? a.dL_dshs + (size_t)i * 48 : nullptr;
 
     if (radius <= 0) {
+        if (use_sh) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) reinterpret_cast<float4*>(dsh)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 12; ++k) reinterpret_cast<float4*>(dsh)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     } else {
         const float4 d0 = dg4[0], d1 = dg4[1], d2 = dg4[2];
         const float g_px = d0.x, g_py = d0.y, gA = d0.z, gB = d0.w, gC = d1.x;
@@ -31,7 +35,10 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
         const float* __restrict__ P = a.projmatrix;
         const float x = a.means3D[3 * i + 0], y = a.means3D[3 * i + 1], z = a.means3D[3 * i + 2];
 
-        // ---- colour: SH backward (clamped channels pass no gradient) ----
+        // ---- colour: SH backward (clamped channels pass no gradient), or straight to colors_precomp ----
+        if (!use_sh) {
+            dcolor[0] = gcol[0]; dcolor[1] = gcol[1]; dcolor[2] = gcol[2];
+        } else {
         const float ddx = x - a.campos[0], ddy = y - a.campos[1], ddz = z - a.campos[2];
         const float nrm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
         const float inv_n = 1.0f / nrm;
@@ -93,25 +100,33 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
         dmean[0] += (gux - ux * udot) * inv_n;
         dmean[1] += (guy - uy * udot) * inv_n;
         dmean[2] += (guz - uz * udot) * inv_n;
+        }
 
         // ---- recompute the forward geometry ----
         const float pvx = V[0] * x + V[4] * y + V[8] * z + V[12];
         const float pvy = V[1] * x + V[5] * y + V[9] * z + V[13];
         const float pvz = V[2] * x + V[6] * y + V[10] * z + V[14];
         const float mod = a.scale_modifier;
-        const float s0 = a.scales[3 * i + 0], s1 = a.scales[3 * i + 1], s2 = a.scales[3 * i + 2];
-        const float sx = mod * s0, sy = mod * s1, sz = mod * s2;
-        const float qr = a.rotations[4 * i + 0], qx = a.rotations[4 * i + 1];
-        const float qy = a.rotations[4 * i + 2], qz = a.rotations[4 * i + 3];
-        const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz), R01 = 2.0f * (qx * qy - qr * qz), R02 = 2.0f * (qx * qz + qr * qy);
-        const float R10 = 2.0f * (qx * qy + qr * qz), R11 = 1.0f - 2.0f * (qx * qx + qz * qz), R12 = 2.0f * (qy * qz - qr * qx);
-        const float R20 = 2.0f * (qx * qz - qr * qy), R21 = 2.0f * (qy * qz + qr * qx), R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
-        const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
-        const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
-        const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
-        const float c00 = M00 * M00 + M01 * M01 + M02 * M02, c01 = M00 * M10 + M01 * M11 + M02 * M12;
-        const float c02 = M00 * M20 + M01 * M21 + M02 * M22, c11 = M10 * M10 + M11 * M11 + M12 * M12;
-        const float c12 = M10 * M20 + M11 * M21 + M12 * M22, c22 = M20 * M20 + M21 * M21 + M22 * M22;
+        float sx = 0.f, sy = 0.f, sz = 0.f, qr = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
+        float R00 = 0.f, R01 = 0.f, R02 = 0.f, R10 = 0.f, R11 = 0.f, R12 = 0.f, R20 = 0.f, R21 = 0.f, R22 = 0.f;
+        float M00 = 0.f, M01 = 0.f, M02 = 0.f, M10 = 0.f, M11 = 0.f, M12 = 0.f, M20 = 0.f, M21 = 0.f, M22 = 0.f;
+        float c00, c01, c02, c11, c12, c22;
+        if (use_cov) {
+            const float* __restrict__ cv = a.cov3D_precomp + (size_t)i * 6;
+            c00 = cv[0]; c01 = cv[1]; c02 = cv[2]; c11 = cv[3]; c12 = cv[4]; c22 = cv[5];
+        } else {
+            sx = mod * a.scales[3 * i + 0]; sy = mod * a.scales[3 * i + 1]; sz = mod * a.scales[3 * i + 2];
+            qr = a.rotations[4 * i + 0]; qx = a.rotations[4 * i + 1]; qy = a.rotations[4 * i + 2]; qz = a.rotations[4 * i + 3];
+            R00 = 1.0f - 2.0f * (qy * qy + qz * qz); R01 = 2.0f * (qx * qy - qr * qz); R02 = 2.0f * (qx * qz + qr * qy);
+            R10 = 2.0f * (qx * qy + qr * qz); R11 = 1.0f - 2.0f * (qx * qx + qz * qz); R12 = 2.0f * (qy * qz - qr * qx);
+            R20 = 2.0f * (qx * qz - qr * qy); R21 = 2.0f * (qy * qz + qr * qx); R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+            M00 = R00 * sx; M01 = R01 * sy; M02 = R02 * sz;
+            M10 = R10 * sx; M11 = R11 * sy; M12 = R12 * sz;
+            M20 = R20 * sx; M21 = R21 * sy; M22 = R22 * sz;
+            c00 = M00 * M00 + M01 * M01 + M02 * M02; c01 = M00 * M10 + M01 * M11 + M02 * M12;
+            c02 = M00 * M20 + M01 * M21 + M02 * M22; c11 = M10 * M10 + M11 * M11 + M12 * M12;
+            c12 = M10 * M20 + M11 * M21 + M12 * M22; c22 = M20 * M20 + M21 * M21 + M22 * M22;
+        }
 
         const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
         const float fx = (float)W / (2.0f * a.tanfovx), fy = (float)H / (2.0f * a.tanfovy);
@@ -165,28 +180,32 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
         dmean[1] += gpvx * V[4] + gpvy * V[5] + gpvz * V[6];
         dmean[2] += gpvx * V[8] + gpvy * V[9] + gpvz * V[10];
 
-        // ---- Sigma = M M^T, M = R diag(s) ----
-        // symmetric gradient matrix Gs: diagonal as is, off-diagonal halves
-        const float h01 = 0.5f * gS01, h02 = 0.5f * gS02, h12 = 0.5f * gS12;
-        const float gM00 = 2.0f * (gS00 * M00 + h01 * M10 + h02 * M20);
-        const float gM01 = 2.0f * (gS00 * M01 + h01 * M11 + h02 * M21);
-        const float gM02 = 2.0f * (gS00 * M02 + h01 * M12 + h02 * M22);
-        const float gM10 = 2.0f * (h01 * M00 + gS11 * M10 + h12 * M20);
-        const float gM11 = 2.0f * (h01 * M01 + gS11 * M11 + h12 * M21);
-        const float gM12 = 2.0f * (h01 * M02 + gS11 * M12 + h12 * M22);
-        const float gM20 = 2.0f * (h02 * M00 + h12 * M10 + gS22 * M20);
-        const float gM21 = 2.0f * (h02 * M01 + h12 * M11 + gS22 * M21);
-        const float gM22 = 2.0f * (h02 * M02 + h12 * M12 + gS22 * M22);
-        dscale[0] = mod * (gM00 * R00 + gM10 * R10 + gM20 * R20);
-        dscale[1] = mod * (gM01 * R01 + gM11 * R11 + gM21 * R21);
-        dscale[2] = mod * (gM02 * R02 + gM12 * R12 + gM22 * R22);
-        const float r00 = gM00 * sx, r01 = gM01 * sy, r02 = gM02 * sz;
-        const float r10 = gM10 * sx, r11 = gM11 * sy, r12 = gM12 * sz;
-        const float r20 = gM20 * sx, r21 = gM21 * sy, r22 = gM22 * sz;
-        drot[0] = 2.0f * (-qz * r01 + qy * r02 + qz * r10 - qx * r12 - qy * r20 + qx * r21);
-        drot[1] = 2.0f * (qy * r01 + qz * r02 + qy * r10 - 2.0f * qx * r11 - qr * r12 + qz * r20 + qr * r21 - 2.0f * qx * r22);
-        drot[2] = 2.0f * (-2.0f * qy * r00 + qx * r01 + qr * r02 + qx * r10 + qz * r12 - qr * r20 + qz * r21 - 2.0f * qy * r22);
-        drot[3] = 2.0f * (-2.0f * qz * r00 - qr * r01 + qx * r02 + qr * r10 - 2.0f * qz * r11 + qy * r12 + qx * r20 + qy * r21);
+        if (use_cov) {
+            dcov[0] = gS00; dcov[1] = gS01; dcov[2] = gS02; dcov[3] = gS11; dcov[4] = gS12; dcov[5] = gS22;
+        } else {
+            // ---- Sigma = M M^T, M = R diag(s) ----
+            // symmetric gradient matrix Gs: diagonal as is, off-diagonal halves
+            const float h01 = 0.5f * gS01, h02 = 0.5f * gS02, h12 = 0.5f * gS12;
+            const float gM00 = 2.0f * (gS00 * M00 + h01 * M10 + h02 * M20);
+            const float gM01 = 2.0f * (gS00 * M01 + h01 * M11 + h02 * M21);
+            const float gM02 = 2.0f * (gS00 * M02 + h01 * M12 + h02 * M22);
+            const float gM10 = 2.0f * (h01 * M00 + gS11 * M10 + h12 * M20);
+            const float gM11 = 2.0f * (h01 * M01 + gS11 * M11 + h12 * M21);
+            const float gM12 = 2.0f * (h01 * M02 + gS11 * M12 + h12 * M22);
+            const float gM20 = 2.0f * (h02 * M00 + h12 * M10 + gS22 * M20);
+            const float gM21 = 2.0f * (h02 * M01 + h12 * M11 + gS22 * M21);
+            const float gM22 = 2.0f * (h02 * M02 + h12 * M12 + gS22 * M22);
+            dscale[0] = mod * (gM00 * R00 + gM10 * R10 + gM20 * R20);
+            dscale[1] = mod * (gM01 * R01 + gM11 * R11 + gM21 * R21);
+            dscale[2] = mod * (gM02 * R02 + gM12 * R12 + gM22 * R22);
+            const float r00 = gM00 * sx, r01 = gM01 * sy, r02 = gM02 * sz;
+            const float r10 = gM10 * sx, r11 = gM11 * sy, r12 = gM12 * sz;
+            const float r20 = gM20 * sx, r21 = gM21 * sy, r22 = gM22 * sz;
+            drot[0] = 2.0f * (-qz * r01 + qy * r02 + qz * r10 - qx * r12 - qy * r20 + qx * r21);
+            drot[1] = 2.0f * (qy * r01 + qz * r02 + qy * r10 - 2.0f * qx * r11 - qr * r12 + qz * r20 + qr * r21 - 2.0f * qx * r22);
+            drot[2] = 2.0f * (-2.0f * qy * r00 + qx * r01 + qr * r02 + qx * r10 + qz * r12 - qr * r20 + qz * r21 - 2.0f * qy * r22);
+            drot[3] = 2.0f * (-2.0f * qz * r00 - qr * r01 + qx * r02 + qr * r10 - 2.0f * qz * r11 + qy * r12 + qx * r20 + qy * r21);
+        }
 
         // ---- pixel position through the perspective projection ----
         dm2x = 0.5f * (float)W * g_px;     // dL/d(ndc x)
@@ -202,12 +221,20 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
         dmean[2] += gphx * P[8] + gphy * P[9] + gphw * P[11];
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        a.dL_dmeans3D[3 * i + k] = dmean[k];
-        a.dL_dscales[3 * i + k] = dscale[k];
-    }
+    for (int k = 0; k < 3; ++k) a.dL_dmeans3D[3 * i + k] = dmean[k];
+    if (use_cov) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a.dL_drotations[4 * i + k] = drot[k];
+        for (int k = 0; k < 6; ++k) a.dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.dL_dscales[3 * i + k] = dscale[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.dL_drotations[4 * i + k] = drot[k];
+    }
+    if (!use_sh) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.dL_dcolors[3 * i + k] = dcolor[k];
+    }
     a.dL_dopacities[i] = dop;
     a.dL_dmeans2D[3 * i + 0] = dm2x;
     a.dL_dmeans2D[3 * i + 1] = dm2y;
@@ -218,9 +245,11 @@ extern "C" int fdgs_raster_preprocess_bwd(const fdgs_preprocess_bwd_args* a, voi
     if (!a || a->num_points < 0 || a->image_width <= 0 || a->image_height <= 0) return FDGS_EINVAL;
     if (a->sh_degree < 0 || a->sh_degree > 3) return FDGS_EINVAL;
     if (a->num_points == 0) return FDGS_OK;
-    if (!a->viewmatrix || !a->projmatrix || !a->campos || !a->means3D || !a->scales || !a->rotations || !a->shs ||
-        !a->geom || !a->dL_dgeom || !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dscales || !a->dL_drotations ||
-        !a->dL_dopacities || !a->dL_dshs)
+    if (!a->viewmatrix || !a->projmatrix || !a->campos || !a->means3D || !a->geom || !a->dL_dgeom ||
+        !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities)
+        return FDGS_EINVAL;
+    if (a->colors_precomp ? !a->dL_dcolors : (!a->shs || !a->dL_dshs)) return FDGS_EINVAL;
+    if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->scales || !a->rotations || !a->dL_dscales || !a->dL_drotations))
         return FDGS_EINVAL;
     hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a->num_points + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        *a);

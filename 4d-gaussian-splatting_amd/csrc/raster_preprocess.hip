@@ -44,29 +44,35 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
         const float ppx = phx * p_w, ppy = phy * p_w;
 
         // 3-D covariance Sigma = (R S)(R S)^T, R as the reference's build_rotation
-        // (src/utils/general_utils.py:108-121) for a normalised (w,x,y,z).
-        const float mod = a.scale_modifier;
-        const float sx = mod * a.scales[3 * i + 0], sy = mod * a.scales[3 * i + 1], sz = mod * a.scales[3 * i + 2];
-        const float qr = a.rotations[4 * i + 0], qx = a.rotations[4 * i + 1];
-        const float qy = a.rotations[4 * i + 2], qz = a.rotations[4 * i + 3];
-        const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz);
-        const float R01 = 2.0f * (qx * qy - qr * qz);
-        const float R02 = 2.0f * (qx * qz + qr * qy);
-        const float R10 = 2.0f * (qx * qy + qr * qz);
-        const float R11 = 1.0f - 2.0f * (qx * qx + qz * qz);
-        const float R12 = 2.0f * (qy * qz - qr * qx);
-        const float R20 = 2.0f * (qx * qz - qr * qy);
-        const float R21 = 2.0f * (qy * qz + qr * qx);
-        const float R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
-        const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
-        const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
-        const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
-        const float c00 = M00 * M00 + M01 * M01 + M02 * M02;
-        const float c01 = M00 * M10 + M01 * M11 + M02 * M12;
-        const float c02 = M00 * M20 + M01 * M21 + M02 * M22;
-        const float c11 = M10 * M10 + M11 * M11 + M12 * M12;
-        const float c12 = M10 * M20 + M11 * M21 + M12 * M22;
-        const float c22 = M20 * M20 + M21 * M21 + M22 * M22;
+        // (src/utils/general_utils.py:108-121) for a normalised (w,x,y,z), unless it is given.
+        float c00, c01, c02, c11, c12, c22;
+        if (a.cov3D_precomp) {
+            const float* __restrict__ cv = a.cov3D_precomp + (size_t)i * 6;
+            c00 = cv[0]; c01 = cv[1]; c02 = cv[2]; c11 = cv[3]; c12 = cv[4]; c22 = cv[5];
+        } else {
+            const float mod = a.scale_modifier;
+            const float sx = mod * a.scales[3 * i + 0], sy = mod * a.scales[3 * i + 1], sz = mod * a.scales[3 * i + 2];
+            const float qr = a.rotations[4 * i + 0], qx = a.rotations[4 * i + 1];
+            const float qy = a.rotations[4 * i + 2], qz = a.rotations[4 * i + 3];
+            const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz);
+            const float R01 = 2.0f * (qx * qy - qr * qz);
+            const float R02 = 2.0f * (qx * qz + qr * qy);
+            const float R10 = 2.0f * (qx * qy + qr * qz);
+            const float R11 = 1.0f - 2.0f * (qx * qx + qz * qz);
+            const float R12 = 2.0f * (qy * qz - qr * qx);
+            const float R20 = 2.0f * (qx * qz - qr * qy);
+            const float R21 = 2.0f * (qy * qz + qr * qx);
+            const float R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+            const float M00 = R00 * sx, M01 = R01 * sy, M02 = R02 * sz;
+            const float M10 = R10 * sx, M11 = R11 * sy, M12 = R12 * sz;
+            const float M20 = R20 * sx, M21 = R21 * sy, M22 = R22 * sz;
+            c00 = M00 * M00 + M01 * M01 + M02 * M02;
+            c01 = M00 * M10 + M01 * M11 + M02 * M12;
+            c02 = M00 * M20 + M01 * M21 + M02 * M22;
+            c11 = M10 * M10 + M11 * M11 + M12 * M12;
+            c12 = M10 * M20 + M11 * M21 + M12 * M22;
+            c22 = M20 * M20 + M21 * M21 + M22 * M22;
+        }
 
         // EWA projection
         const float limx = 1.3f * a.tanfovx, limy = 1.3f * a.tanfovy;
@@ -116,7 +122,9 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
                 touched = (uint32_t)area;
             }
         }
-        if (visible) {
+        if (visible && a.colors_precomp) {
+            cr = a.colors_precomp[3 * i + 0]; cg = a.colors_precomp[3 * i + 1]; cb = a.colors_precomp[3 * i + 2];
+        } else if (visible) {
             // colour from SH, basis and signs as src/utils/sh_utils.py:57-100
             const float ddx = x - a.campos[0], ddy = y - a.campos[1], ddz = z - a.campos[2];
             const float nrm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
@@ -307,10 +315,11 @@ extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, voi
     if (a->sh_degree < 0 || a->sh_degree > 3) return FDGS_EINVAL;
     const int n = a->num_points;
     if (n == 0) return FDGS_OK;
-    if (!a->viewmatrix || !a->projmatrix || !a->campos || !a->means3D || !a->scales || !a->rotations ||
-        !a->opacities || !a->shs || !a->geom || !a->radii || !a->tiles_touched || !a->point_offsets ||
-        !a->scan_workspace)
+    if (!a->viewmatrix || !a->projmatrix || !a->campos || !a->means3D || !a->opacities || !a->geom || !a->radii ||
+        !a->tiles_touched || !a->point_offsets || !a->scan_workspace)
         return FDGS_EINVAL;
+    if (!a->colors_precomp && !a->shs) return FDGS_EINVAL;
+    if (!a->cov3D_precomp && (!a->scales || !a->rotations)) return FDGS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *a);
     FDGS_CHECK_LAUNCH();

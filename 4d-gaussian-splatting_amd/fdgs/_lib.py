@@ -28,6 +28,7 @@ class PreprocessFwdArgs(C.Structure):
                 ("tanfovx", c_f), ("tanfovy", c_f), ("scale_modifier", c_f),
                 ("viewmatrix", c_p), ("projmatrix", c_p), ("campos", c_p),
                 ("means3D", c_p), ("scales", c_p), ("rotations", c_p), ("opacities", c_p), ("shs", c_p),
+                ("colors_precomp", c_p), ("cov3D_precomp", c_p),
                 ("geom", c_p), ("radii", c_p), ("tiles_touched", c_p), ("point_offsets", c_p),
                 ("scan_workspace", c_p)]
 
@@ -56,9 +57,10 @@ class PreprocessBwdArgs(C.Structure):
                 ("tanfovx", c_f), ("tanfovy", c_f), ("scale_modifier", c_f),
                 ("viewmatrix", c_p), ("projmatrix", c_p), ("campos", c_p),
                 ("means3D", c_p), ("scales", c_p), ("rotations", c_p), ("shs", c_p),
+                ("colors_precomp", c_p), ("cov3D_precomp", c_p),
                 ("geom", c_p), ("dL_dgeom", c_p),
                 ("dL_dmeans3D", c_p), ("dL_dmeans2D", c_p), ("dL_dscales", c_p), ("dL_drotations", c_p),
-                ("dL_dopacities", c_p), ("dL_dshs", c_p)]
+                ("dL_dopacities", c_p), ("dL_dshs", c_p), ("dL_dcolors", c_p), ("dL_dcov3D", c_p)]
 
 
 class DeformParams(C.Structure):
@@ -104,7 +106,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def _load():

@@ -46,9 +46,12 @@ class RasterState:
                  "ranges", "final_T", "n_contrib", "color", "depth")
 
 
-def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=False):
-    """Runs stages 1-6 through the C ABI and returns a RasterState."""
-    _lib.require_gpu(means3D, shs, opacities, scales, rotations, S.bg, S.viewmatrix, S.projmatrix, S.campos)
+def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=False, colors_precomp=None,
+                      cov3D_precomp=None):
+    """Runs stages 1-6 through the C ABI and returns a RasterState.  Either shs or colors_precomp [N,3],
+    either (scales, rotations) or cov3D_precomp [N,6]."""
+    _lib.require_gpu(means3D, shs, opacities, scales, rotations, colors_precomp, cov3D_precomp, S.bg, S.viewmatrix,
+                     S.projmatrix, S.campos)
     dev = means3D.device
     N = means3D.shape[0]
     H, W = int(S.image_height), int(S.image_width)
@@ -64,7 +67,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
 
     a = _lib.PreprocessFwdArgs(N, int(S.sh_degree), W, H, float(S.tanfovx), float(S.tanfovy), float(S.scale_modifier),
                                ptr(vm), ptr(pm), ptr(cp), ptr(means3D), ptr(scales), ptr(rotations), ptr(opacities),
-                               ptr(shs), ptr(st.geom), ptr(st.radii), ptr(st.tiles_touched), ptr(st.point_offsets),
+                               ptr(shs), ptr(colors_precomp), ptr(cov3D_precomp), ptr(st.geom), ptr(st.radii), ptr(st.tiles_touched), ptr(st.point_offsets),
                                ptr(scan_ws))
     _lib.call("fdgs_raster_preprocess_fwd", a)
 
@@ -96,7 +99,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     return st
 
 
-def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S):
+def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, colors_precomp=None, cov3D_precomp=None):
     dev = means3D.device
     N = means3D.shape[0]
     H, W = int(S.image_height), int(S.image_width)
@@ -109,37 +112,49 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S):
     _lib.call("fdgs_raster_blend_bwd", a)
     d_means3D = torch.empty(N, 3, device=dev, dtype=torch.float32)
     d_means2D = torch.empty(N, 3, device=dev, dtype=torch.float32)
-    d_scales = torch.empty(N, 3, device=dev, dtype=torch.float32)
-    d_rot = torch.empty(N, 4, device=dev, dtype=torch.float32)
+    d_scales = d_rot = d_shs = d_colors = d_cov = None
+    if cov3D_precomp is None:
+        d_scales = torch.empty(N, 3, device=dev, dtype=torch.float32)
+        d_rot = torch.empty(N, 4, device=dev, dtype=torch.float32)
+    else:
+        d_cov = torch.empty(N, 6, device=dev, dtype=torch.float32)
     d_op = torch.empty(N, 1, device=dev, dtype=torch.float32)
-    d_shs = torch.empty(N, 16, 3, device=dev, dtype=torch.float32)
+    if colors_precomp is None:
+        d_shs = torch.empty(N, 16, 3, device=dev, dtype=torch.float32)
+    else:
+        d_colors = torch.empty(N, 3, device=dev, dtype=torch.float32)
     b = _lib.PreprocessBwdArgs(N, int(S.sh_degree), W, H, float(S.tanfovx), float(S.tanfovy),
                                float(S.scale_modifier), ptr(vm), ptr(pm), ptr(cp), ptr(means3D), ptr(scales),
-                               ptr(rotations), ptr(shs), ptr(st.geom), ptr(dgeom), ptr(d_means3D), ptr(d_means2D),
-                               ptr(d_scales), ptr(d_rot), ptr(d_op), ptr(d_shs))
+                               ptr(rotations), ptr(shs), ptr(colors_precomp), ptr(cov3D_precomp), ptr(st.geom),
+                               ptr(dgeom), ptr(d_means3D), ptr(d_means2D), ptr(d_scales), ptr(d_rot), ptr(d_op),
+                               ptr(d_shs), ptr(d_colors), ptr(d_cov))
     _lib.call("fdgs_raster_preprocess_bwd", b)
-    return d_means3D, d_means2D, d_shs, d_op, d_scales, d_rot, dgeom
+    return dict(means3D=d_means3D, means2D=d_means2D, shs=d_shs, colors=d_colors, opacities=d_op, scales=d_scales,
+                rotations=d_rot, cov3D=d_cov, geom=dgeom)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, opacities, scales, rotations, S):
-        m3, sh = _f32c(means3D), _f32c(shs)
-        op, sc, ro = _f32c(opacities).reshape(-1), _f32c(scales), _f32c(rotations)
-        st = rasterize_forward(m3, sh, op, sc, ro, S)
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, S):
+        opt = lambda t: None if t is None else _f32c(t)
+        m3, sh, cp = _f32c(means3D), opt(shs), opt(colors_precomp)
+        op, sc, ro, cv = _f32c(opacities).reshape(-1), opt(scales), opt(rotations), opt(cov3D_precomp)
+        st = rasterize_forward(m3, sh, op, sc, ro, S, colors_precomp=cp, cov3D_precomp=cv)
         ctx.S = S
         ctx.st = st
-        ctx.save_for_backward(m3, sh, sc, ro)
+        ctx.inputs = (m3, sh, cp, sc, ro, cv)
         ctx.op_shape = opacities.shape
         ctx.mark_non_differentiable(st.radii, st.depth)
         return st.color, st.radii, st.depth
 
     @staticmethod
     def backward(ctx, grad_color, _grad_radii, _grad_depth):
-        m3, sh, sc, ro = ctx.saved_tensors
-        d_m3, d_m2, d_sh, d_op, d_sc, d_ro, _ = rasterize_backward(ctx.st, grad_color, m3, sh, sc, ro, ctx.S)
+        m3, sh, cp, sc, ro, cv = ctx.inputs
+        g = rasterize_backward(ctx.st, grad_color, m3, sh, sc, ro, ctx.S, colors_precomp=cp, cov3D_precomp=cv)
         ctx.st = None
-        return d_m3, d_m2, d_sh, d_op.reshape(ctx.op_shape), d_sc, d_ro, None
+        ctx.inputs = None
+        return (g["means3D"], g["means2D"], g["shs"], g["colors"], g["opacities"].reshape(ctx.op_shape), g["scales"],
+                g["rotations"], g["cov3D"], None)
 
 
 class GaussianRasterizer(nn.Module):
@@ -149,11 +164,12 @@ class GaussianRasterizer(nn.Module):
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                 cov3D_precomp=None):
-        if shs is None or colors_precomp is not None:
-            raise NotImplementedError("colors_precomp (convert_SHs_python / override_color) is not built yet: "
-                                      "pass shs and let the rasterizer evaluate them")
-        if cov3D_precomp is not None or scales is None or rotations is None:
-            raise NotImplementedError("cov3D_precomp (compute_cov3D_python) is not built yet: pass scales and rotations")
-        if shs.shape[1:] != (16, 3):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide exactly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if shs is not None and tuple(shs.shape[1:]) != (16, 3):
             raise ValueError("shs must be [N,16,3] (SH degree 3 storage)")
-        return _RasterizeGaussians.apply(means3D, means2D, shs, opacities, scales, rotations, self.raster_settings)
+        return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                         cov3D_precomp, self.raster_settings)

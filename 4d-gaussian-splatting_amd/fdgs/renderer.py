@@ -6,6 +6,11 @@
 (src/model/gaussian_model.py:70-89: get_xyz, _scaling, _rotation, _opacity,
 get_features, active_sh_degree, the three activation callables); `deforms` is
 any object whose `deformation_fields` is callable like DeformationFields.
+
+The reference forwards `shs` together with `colors_precomp` when
+`override_color` / `convert_SHs_python` are used (:89-113), which its
+rasterizer wrapper rejects; here `shs` is dropped in those two cases so the
+flags do what their comments describe.
 """
 import math
 
@@ -45,14 +50,23 @@ def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifi
     means2D = screenspace_points
     opacity = pc._opacity
     shs = pc.get_features
+    scales = None
+    rotations = None
+    cov3D_precomp = None
     if compute_cov3D_python:
-        raise NotImplementedError("compute_cov3D_python: pass scales/rotations (the rasterizer builds the covariance)")
-    scales = pc._scaling
-    rotations = pc._rotation
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales = pc._scaling
+        rotations = pc._rotation
 
     if "coarse" in stage:
         means3D_final, scales_final, rotations_final, opacity_final, shs_final = means3D, scales, rotations, opacity, shs
     elif "fine" in stage:
+        if compute_cov3D_python:
+            # the reference hands scales=None to the deformation field here and fails inside it
+            # (src/gaussian_renderer/__init__.py:70-81); a precomputed covariance cannot be deformed
+            raise ValueError("compute_cov3D_python is only usable with stage='coarse': the deformation field "
+                             "needs scales and rotations")
         # the reference materialises time as an [N,1] tensor (:52); a python float reaches the same
         # kernel through its scalar-time argument without the N-element allocation
         means3D_final, scales_final, rotations_final, opacity_final, shs_final = deforms.deformation_fields(
@@ -60,17 +74,28 @@ def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifi
     else:
         raise NotImplementedError
 
-    scales_final = pc.scaling_activation(scales_final)
-    rotations_final = pc.rotation_activation(rotations_final)
+    if scales_final is not None:
+        scales_final = pc.scaling_activation(scales_final)
+        rotations_final = pc.rotation_activation(rotations_final)
     opacity = pc.opacity_activation(opacity_final)
 
-    if override_color is not None or convert_SHs_python:
-        raise NotImplementedError("colors_precomp path (override_color / convert_SHs_python) is not built; "
-                                  "SH evaluation happens inside the rasterizer")
+    colors_precomp = None
+    if override_color is None:
+        if convert_SHs_python:      # SH -> RGB on the host side, as gaussian_renderer/__init__.py:91-96
+            from .sh import eval_sh
+            shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+            dir_pp = pc.get_xyz - viewpoint_camera.camera_center.to(dev).repeat(pc.get_features.shape[0], 1)
+            dir_pp_normalized = dir_pp / dir_pp.norm(dim=1, keepdim=True)
+            sh2rgb = eval_sh(pc.active_sh_degree, shs_view, dir_pp_normalized)
+            colors_precomp = torch.clamp_min(sh2rgb + 0.5, 0.0)
+            shs_final = None
+    else:
+        colors_precomp = override_color
+        shs_final = None
 
     rendered_image, radii, depth = rasterizer(
-        means3D=means3D_final, means2D=means2D, shs=shs_final, colors_precomp=None, opacities=opacity,
-        scales=scales_final, rotations=rotations_final, cov3D_precomp=None)
+        means3D=means3D_final, means2D=means2D, shs=shs_final, colors_precomp=colors_precomp, opacities=opacity,
+        scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp)
     return {"render": rendered_image,
             "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0,

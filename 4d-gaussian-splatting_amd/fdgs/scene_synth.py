@@ -138,6 +138,19 @@ class GaussianParams:
     def get_features(self):
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 
+    def get_covariance(self, scaling_modifier=1):
+        """Upper triangle of R S S^T R^T as src/model/gaussian_model.py:38-42,92-93
+        (rotation normalised inside, src/utils/general_utils.py:101-133)."""
+        s = scaling_modifier * torch.exp(self._scaling)
+        q = self._rotation / self._rotation.norm(dim=1, keepdim=True)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+        L = R * s[:, None, :]
+        cov = L @ L.transpose(1, 2)
+        return torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], dim=1)
+
     def parameters(self):
         return [self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling, self._rotation]
 

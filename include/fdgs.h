@@ -69,10 +69,14 @@ typedef struct {
     const float* projmatrix;         /* [16]                                        */
     const float* campos;             /* [3]                                         */
     const float* means3D;            /* [N,3]                                       */
-    const float* scales;             /* [N,3] activated (exp already applied)       */
-    const float* rotations;          /* [N,4] normalised                            */
+    const float* scales;             /* [N,3] activated (exp already applied); NULL with cov3D_precomp */
+    const float* rotations;          /* [N,4] normalised; NULL with cov3D_precomp   */
     const float* opacities;          /* [N]   activated (sigmoid already applied)   */
-    const float* shs;                /* [N,16,3]                                    */
+    const float* shs;                /* [N,16,3]; may be NULL when colors_precomp is given */
+    const float* colors_precomp;     /* [N,3] RGB used as is (no SH evaluation, no clamp), or NULL
+                                        (src/gaussian_renderer/__init__.py:89-101)  */
+    const float* cov3D_precomp;      /* [N,6] upper triangle of the world-space covariance (scale modifier already
+                                        applied), or NULL to build it from scales / rotations (:70-74)       */
     /* outputs */
     float* geom;                     /* [N,12] packed record (see above)            */
     int32_t* radii;                  /* [N]   0 = not visible                       */
@@ -151,6 +155,8 @@ typedef struct {
     const float* scales;
     const float* rotations;
     const float* shs;
+    const float* colors_precomp;     /* as in the forward (NULL: SH path)            */
+    const float* cov3D_precomp;      /* as in the forward (NULL: scales/rotations)   */
     const float* geom;               /* [N,12] from the forward (radius, clamp mask) */
     const float* dL_dgeom;           /* [N,12] from fdgs_raster_blend_bwd            */
     /* outputs (fully written, no need to zero) */
@@ -159,7 +165,9 @@ typedef struct {
     float* dL_dscales;               /* [N,3]  w.r.t. the activated scales          */
     float* dL_drotations;            /* [N,4]  w.r.t. the normalised quaternion     */
     float* dL_dopacities;            /* [N]                                         */
-    float* dL_dshs;                  /* [N,16,3]                                    */
+    float* dL_dshs;                  /* [N,16,3]   (SH path)                        */
+    float* dL_dcolors;               /* [N,3]      (colors_precomp path)            */
+    float* dL_dcov3D;                /* [N,6]      (cov3D_precomp path)             */
 } fdgs_preprocess_bwd_args;
 
 int fdgs_raster_preprocess_bwd(const fdgs_preprocess_bwd_args* a, void* stream);

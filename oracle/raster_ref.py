@@ -100,7 +100,7 @@ def eval_sh_color(deg, sh, dx, dy, dz):
     return res
 
 
-def preprocess(means3D, scales, rotations, opacities, shs, S, means2D=None):
+def preprocess(means3D, scales, rotations, opacities, shs, S, means2D=None, colors_precomp=None, cov3D_precomp=None):
     """Stage 1, per Gaussian.  scales are already exp-activated, rotations
     already normalised, opacities already sigmoid-activated
     (src/gaussian_renderer/__init__.py:85-87).  Matrices are the row-vector
@@ -127,28 +127,31 @@ def preprocess(means3D, scales, rotations, opacities, shs, S, means2D=None):
     ppx = phx * p_w
     ppy = phy * p_w
 
-    # 3-D covariance  Sigma = (R S)(R S)^T, R as src/utils/general_utils.py:108-121
-    mod = torch.tensor(S.scale_modifier, dtype=dt)
-    sx, sy, sz = mod * scales[:, 0], mod * scales[:, 1], mod * scales[:, 2]
-    qr, qx, qy, qz = rotations[:, 0], rotations[:, 1], rotations[:, 2], rotations[:, 3]
-    R00 = 1.0 - 2.0 * (qy * qy + qz * qz)
-    R01 = 2.0 * (qx * qy - qr * qz)
-    R02 = 2.0 * (qx * qz + qr * qy)
-    R10 = 2.0 * (qx * qy + qr * qz)
-    R11 = 1.0 - 2.0 * (qx * qx + qz * qz)
-    R12 = 2.0 * (qy * qz - qr * qx)
-    R20 = 2.0 * (qx * qz - qr * qy)
-    R21 = 2.0 * (qy * qz + qr * qx)
-    R22 = 1.0 - 2.0 * (qx * qx + qy * qy)
-    M00, M01, M02 = R00 * sx, R01 * sy, R02 * sz
-    M10, M11, M12 = R10 * sx, R11 * sy, R12 * sz
-    M20, M21, M22 = R20 * sx, R21 * sy, R22 * sz
-    c00 = M00 * M00 + M01 * M01 + M02 * M02
-    c01 = M00 * M10 + M01 * M11 + M02 * M12
-    c02 = M00 * M20 + M01 * M21 + M02 * M22
-    c11 = M10 * M10 + M11 * M11 + M12 * M12
-    c12 = M10 * M20 + M11 * M21 + M12 * M22
-    c22 = M20 * M20 + M21 * M21 + M22 * M22
+    if cov3D_precomp is not None:      # src/gaussian_renderer/__init__.py:70-71 (compute_cov3D_python)
+        c00, c01, c02, c11, c12, c22 = (cov3D_precomp[:, k] for k in range(6))
+    else:
+        # 3-D covariance  Sigma = (R S)(R S)^T, R as src/utils/general_utils.py:108-121
+        mod = torch.tensor(S.scale_modifier, dtype=dt)
+        sx, sy, sz = mod * scales[:, 0], mod * scales[:, 1], mod * scales[:, 2]
+        qr, qx, qy, qz = rotations[:, 0], rotations[:, 1], rotations[:, 2], rotations[:, 3]
+        R00 = 1.0 - 2.0 * (qy * qy + qz * qz)
+        R01 = 2.0 * (qx * qy - qr * qz)
+        R02 = 2.0 * (qx * qz + qr * qy)
+        R10 = 2.0 * (qx * qy + qr * qz)
+        R11 = 1.0 - 2.0 * (qx * qx + qz * qz)
+        R12 = 2.0 * (qy * qz - qr * qx)
+        R20 = 2.0 * (qx * qz - qr * qy)
+        R21 = 2.0 * (qy * qz + qr * qx)
+        R22 = 1.0 - 2.0 * (qx * qx + qy * qy)
+        M00, M01, M02 = R00 * sx, R01 * sy, R02 * sz
+        M10, M11, M12 = R10 * sx, R11 * sy, R12 * sz
+        M20, M21, M22 = R20 * sx, R21 * sy, R22 * sz
+        c00 = M00 * M00 + M01 * M01 + M02 * M02
+        c01 = M00 * M10 + M01 * M11 + M02 * M12
+        c02 = M00 * M20 + M01 * M21 + M02 * M22
+        c11 = M10 * M10 + M11 * M11 + M12 * M12
+        c12 = M10 * M20 + M11 * M21 + M12 * M22
+        c22 = M20 * M20 + M21 * M21 + M22 * M22
 
     # EWA projection to a 2-D covariance
     tanx = torch.tensor(S.tanfovx, dtype=dt)
@@ -211,13 +214,17 @@ def preprocess(means3D, scales, rotations, opacities, shs, S, means2D=None):
         radii = torch.where(visible, rad_f.to(torch.int32), torch.zeros_like(area))
         tiles_touched = torch.where(visible, area, torch.zeros_like(area))
 
-    # colour from SH (view direction from the camera centre to the mean)
-    ddx, ddy, ddz = x - cam[0], y - cam[1], z - cam[2]
-    nrm = torch.sqrt(ddx * ddx + ddy * ddy + ddz * ddz)
-    ux, uy, uz = (ddx / nrm)[:, None], (ddy / nrm)[:, None], (ddz / nrm)[:, None]
-    raw = eval_sh_color(S.sh_degree, shs, ux, uy, uz) + 0.5
-    clamped = raw.detach() < 0
-    rgb = torch.where(clamped, torch.zeros_like(raw), raw)
+    if colors_precomp is not None:     # src/gaussian_renderer/__init__.py:89-101: used as is
+        rgb = colors_precomp
+        clamped = torch.zeros_like(rgb, dtype=torch.bool)
+    else:
+        # colour from SH (view direction from the camera centre to the mean)
+        ddx, ddy, ddz = x - cam[0], y - cam[1], z - cam[2]
+        nrm = torch.sqrt(ddx * ddx + ddy * ddy + ddz * ddz)
+        ux, uy, uz = (ddx / nrm)[:, None], (ddy / nrm)[:, None], (ddz / nrm)[:, None]
+        raw = eval_sh_color(S.sh_degree, shs, ux, uy, uz) + 0.5
+        clamped = raw.detach() < 0
+        rgb = torch.where(clamped, torch.zeros_like(raw), raw)
 
     if means2D is not None:   # gradient carrier (value is zero)
         px = px + (0.5 * W) * means2D[:, 0]
@@ -332,11 +339,13 @@ def blend(pre, sorted_vals, ranges, S, tiles=None):
     return color, depth, outs[2][..., 0], outs[3][..., 0]
 
 
-def rasterize(means3D, means2D, shs, opacities, scales, rotations, S, tiles=None, return_aux=False):
-    """The call of src/gaussian_renderer/__init__.py:104-113 (colors_precomp and
-    cov3D_precomp None): returns (color [3,H,W], radii [N] int32, depth [1,H,W]).
-    Differentiable (autograd) w.r.t. means3D, means2D, shs, opacities, scales, rotations."""
-    pre = preprocess(means3D, scales, rotations, opacities, shs, S, means2D)
+def rasterize(means3D, means2D, shs, opacities, scales, rotations, S, tiles=None, return_aux=False,
+              colors_precomp=None, cov3D_precomp=None):
+    """The call of src/gaussian_renderer/__init__.py:104-113: returns (color [3,H,W],
+    radii [N] int32, depth [1,H,W]).  Either shs or colors_precomp [N,3]; either
+    (scales, rotations) or cov3D_precomp [N,6] (xx,xy,xz,yy,yz,zz, scale modifier applied).
+    Differentiable (autograd) w.r.t. every floating-point input given."""
+    pre = preprocess(means3D, scales, rotations, opacities, shs, S, means2D, colors_precomp, cov3D_precomp)
     keys, vals, offsets = build_keys(pre, S)
     skeys, svals = sort_keys(keys, vals)
     gx, gy = tile_grid(S)

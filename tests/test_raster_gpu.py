@@ -114,3 +114,80 @@ def test_no_grad_and_empty():
     assert int((rad > 0).sum()) == 0
     assert torch.allclose(img.cpu(), S.bg.reshape(3, 1, 1).expand(3, S.image_height, S.image_width))
     assert float(dep.abs().max()) == 0.0
+
+
+def _cov6(scales, rotations):
+    """Upper triangle of (R S)(R S)^T, float64 then rounded once, so both sides get identical inputs."""
+    q = rotations.double()
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=1).reshape(-1, 3, 3)
+    L = R * scales.double()[:, None, :]
+    c = L @ L.transpose(1, 2)
+    return torch.stack([c[:, 0, 0], c[:, 0, 1], c[:, 0, 2], c[:, 1, 1], c[:, 1, 2], c[:, 2, 2]], 1).float().contiguous()
+
+
+@pytest.mark.parametrize("name", ["small", "ragged"])
+def test_precomputed_color_and_covariance(name):
+    """colors_precomp / cov3D_precomp inputs (src/gaussian_renderer/__init__.py:66-101,104-113):
+    same integer stages, image and gradients as the oracle given the same precomputed tensors."""
+    from fdgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    c = rc.make_case(name)
+    N = c["means3D"].shape[0]
+    gen = torch.Generator().manual_seed(7)
+    colors = torch.rand(N, 3, generator=gen) * 1.2 - 0.1        # some negative: used as is, no clamp
+    cov = _cov6(c["scales"], c["rotations"])
+    S = c["S"]
+
+    ins = {"means3D": c["means3D"].clone().requires_grad_(True), "opacities": c["opacities"].clone().requires_grad_(True),
+           "colors": colors.clone().requires_grad_(True), "cov": cov.clone().requires_grad_(True)}
+    m2 = torch.zeros(N, 3, requires_grad=True)
+    color, radii, depth, aux = rr.rasterize(ins["means3D"], m2, None, ins["opacities"], None, None, S, return_aux=True,
+                                            colors_precomp=ins["colors"], cov3D_precomp=ins["cov"])
+    gout = torch.randn(color.shape, generator=gen)
+    (color * gout).sum().backward()
+
+    dev = torch.device("cuda:0")
+    gs = GaussianRasterizationSettings(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.bg.to(dev),
+                                       S.scale_modifier, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.sh_degree,
+                                       S.campos.to(dev), False, False)
+    d = {"means3D": c["means3D"].to(dev).requires_grad_(True), "opacities": c["opacities"].to(dev).requires_grad_(True),
+         "colors": colors.to(dev).requires_grad_(True), "cov": cov.to(dev).requires_grad_(True)}
+    m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+    img, rad, dep = GaussianRasterizer(gs)(means3D=d["means3D"], means2D=m2d, shs=None, colors_precomp=d["colors"],
+                                           opacities=d["opacities"], scales=None, rotations=None,
+                                           cov3D_precomp=d["cov"])
+    (img * gout.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.equal(rad.cpu(), radii)
+    assert float((img.cpu() - color).abs().max()) <= IMG_TOL
+    dtol = IMG_TOL * max(1.0, float(depth.abs().max()))
+    assert float((dep.cpu() - depth).abs().max()) <= dtol
+    for k, got, ref in [("means2D", m2d.grad, m2.grad)] + [(k, d[k].grad, ins[k].grad) for k in d]:
+        got = got.cpu()
+        assert got.shape == ref.shape, k
+        assert torch.isfinite(got).all(), k
+        rel = float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+        assert rel <= GRAD_TOL, f"{k}: rel {rel:.3e}"
+
+
+def test_rasterizer_argument_checks():
+    """Same exceptions as the reference wrapper for ambiguous colour / covariance inputs."""
+    from fdgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    c = rc.make_case("deg0")
+    dev = torch.device("cuda:0")
+    S = c["S"]
+    gs = GaussianRasterizationSettings(S.image_height, S.image_width, S.tanfovx, S.tanfovy, S.bg.to(dev),
+                                       S.scale_modifier, S.viewmatrix.to(dev), S.projmatrix.to(dev), S.sh_degree,
+                                       S.campos.to(dev), False, False)
+    r = GaussianRasterizer(gs)
+    m = c["means3D"].to(dev)
+    kw = dict(means3D=m, means2D=torch.zeros_like(m), opacities=c["opacities"].to(dev))
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(shs=None, colors_precomp=None, scales=c["scales"].to(dev), rotations=c["rotations"].to(dev), **kw)
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        r(shs=c["shs"].to(dev), colors_precomp=torch.zeros_like(m), scales=c["scales"].to(dev),
+          rotations=c["rotations"].to(dev), **kw)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(shs=c["shs"].to(dev), scales=None, rotations=None, cov3D_precomp=None, **kw)

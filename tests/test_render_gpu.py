@@ -1,0 +1,69 @@
+"""GPU: the render() drop-in end to end, including the host-side colour and
+covariance flags of src/gaussian_renderer/__init__.py:21-120."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n=4000, w=160, h=120):
+    from fdgs import scene_synth as ss
+    from fdgs.deformation import DeformationFields
+    dev = torch.device("cuda:0")
+    cam = ss.make_cameras(3, w, h, device=dev)[1]
+    pc = ss.GaussianParams(n, device=dev, scale_mult=4.0)
+    torch.manual_seed(0)
+    from fdgs.train_step import DeformHolder
+    net = ss.perturb_deformation_(DeformationFields(ss.DYNERF_NET_KWARGS)).to(dev)
+    return cam, pc, DeformHolder(net), torch.ones(3, device=dev)
+
+
+def _grads(pc):
+    out = [p.grad.clone() for p in pc.parameters()]
+    for p in pc.parameters():
+        p.grad = None
+    return out
+
+
+def test_render_contract_and_flags():
+    from fdgs.renderer import render
+    cam, pc, deforms, bg = _scene()
+    gen = torch.Generator().manual_seed(3)
+    gout = torch.randn(3, cam.image_height, cam.image_width, generator=gen).cuda()
+
+    for stage in ("coarse", "fine"):
+        out = render(cam, pc, deforms, bg, stage=stage)
+        assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
+        assert out["render"].shape == (3, cam.image_height, cam.image_width)
+        assert out["depth"].shape == (1, cam.image_height, cam.image_width)
+        assert out["radii"].dtype == torch.int32 and out["visibility_filter"].dtype == torch.bool
+        (out["render"] * gout).sum().backward()
+        assert out["viewspace_points"].grad is not None and out["viewspace_points"].grad.shape == pc.get_xyz.shape
+        base = (out["render"].detach(), out["radii"].clone(), _grads(pc))
+
+        # SH evaluated on the host: same colours up to rounding (direction from the undeformed centre in
+        # both, so only exact for the coarse stage)
+        if stage == "coarse":
+            o2 = render(cam, pc, deforms, bg, stage=stage, convert_SHs_python=True)
+            assert torch.equal(o2["radii"], base[1])
+            assert float((o2["render"] - base[0]).abs().max()) <= 1e-5
+            (o2["render"] * gout).sum().backward()
+            g2 = _grads(pc)
+            for a, b in zip(g2, base[2]):
+                assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 1e-4
+            # covariance built on the host
+            o3 = render(cam, pc, deforms, bg, stage=stage, compute_cov3D_python=True)
+            assert float((o3["render"] - base[0]).abs().max()) <= 1e-4
+            assert int((o3["radii"] != base[1]).sum()) <= max(2, base[1].numel() // 500)   # ceil(3 sigma) ties
+            (o3["render"] * gout).sum().backward()
+            g3 = _grads(pc)
+            for a, b in zip(g3, base[2]):
+                assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 2e-3
+        else:
+            with pytest.raises(ValueError):
+                render(cam, pc, deforms, bg, stage=stage, compute_cov3D_python=True)
+
+        # override_color: constant colour -> image is colour * (1 - T) + bg * T
+        col = torch.full((pc.get_xyz.shape[0], 3), 0.25, device="cuda")
+        o4 = render(cam, pc, deforms, bg, stage=stage, override_color=col)
+        assert float(o4["render"].min()) >= 0.25 - 1e-5 and float(o4["render"].max()) <= 1.0 + 1e-5
