@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collects the judged artifacts on the GPU box (run through gpurun from the repo root):
+#   gpurun_out/prof/stats   rocprofv3 --kernel-trace --stats of `bench.py --steps 20`
+#   gpurun_out/prof/fetch, gpurun_out/prof/write   one PMC pass each (FETCH_SIZE, WRITE_SIZE)
+#   gpurun_out/bench.json   the plain bench line (with the CPU baseline)
+# Every GPU step has its own time limit and the chain stops at the first failure.
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out
+mkdir -p $OUT/prof
+cd /tmp && export TMPDIR=/tmp
+B="$ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --render-frames 0"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/stats -o stats --output-format csv -- python3 $B > $OUT/prof/stats.log 2>&1
+echo "stats pass done"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof/fetch -o fetch --output-format csv -- python3 $B > $OUT/prof/fetch.log 2>&1
+echo "fetch pass done"
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/prof/write -o write --output-format csv -- python3 $B > $OUT/prof/write.log 2>&1
+echo "write pass done"
+cd $ROOT
+F=$(find $OUT/prof/fetch -name '*counter_collection.csv' | head -1)
+W=$(find $OUT/prof/write -name '*counter_collection.csv' | head -1)
+python3 tools/pmc_summary.py "$F" "$W" $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
+cp "$(find $OUT/prof/stats -name '*kernel_stats.csv' | head -1)" $OUT/kernel_stats.csv
+# keep the merged-back directory small: the raw per-dispatch CSVs are not needed afterwards
+find $OUT/prof -name '*counter_collection.csv' -delete
+find $OUT/prof -name '*kernel_trace.csv' -delete
+timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+tail -c 3000 $OUT/bench.json
