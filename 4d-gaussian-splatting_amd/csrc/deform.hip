@@ -452,6 +452,8 @@ __device__ __forceinline__ void wide_layer128(const float* packed, int ib, int l
     }
 }
 
+#include "deform_split.h"
+
 // ---------------------------------------------------------------------------
 // Host side
 // ---------------------------------------------------------------------------
@@ -465,6 +467,7 @@ static bool params_ok(const fdgs_deform_params* p) {
             if (p->res[l][k] < 2) return false;
     for (int h = 0; h < 5; ++h)
         if (!p->w1[h] || !p->b1[h] || !p->w2[h] || !p->b2[h]) return false;
+    if (p->matmul != FDGS_MATMUL_F32 && p->matmul != FDGS_MATMUL_SPLIT_BF16) return false;
     return true;
 }
 
@@ -481,7 +484,12 @@ static size_t total_plane_floats(const fdgs_deform_params* p) {
 
 static const int h_head_dim[5] = {3, 3, 4, 1, 48};
 
-static size_t fwd_packed_floats() {
+static size_t fwd_packed_floats(int matmul) {
+    if (matmul == FDGS_MATMUL_SPLIT_BF16) {
+        size_t t = sfrag_vec4(DW, 32);
+        for (int h = 0; h < 5; ++h) t += sfrag_vec4(DW, DW) + sfrag_vec4(h_head_dim[h], DW);
+        return 4 * t;
+    }
     size_t t = frag_floats(DW, 32);
     for (int h = 0; h < 5; ++h) t += frag_floats(DW, DW) + frag_floats(h_head_dim[h], DW);
     return t;
@@ -492,9 +500,17 @@ static size_t bwd_packed_floats() {
     return t;
 }
 
-extern "C" size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p) {
-    if (!p || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS) return 0;
-    return (total_plane_floats(p) + fwd_packed_floats()) * sizeof(float);
+static size_t fwd_split_bias_floats();
+static size_t fwd_split_feat_floats(int n);
+
+extern "C" size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points) {
+    if (!p || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS || num_points < 0) return 0;
+    size_t floats = total_plane_floats(p) + fwd_packed_floats(p->matmul);
+    if (p->matmul == FDGS_MATMUL_SPLIT_BF16) floats += fwd_split_bias_floats() + fwd_split_feat_floats(num_points);
+#ifdef EXP_STAMP
+    floats += (1 << 18);
+#endif
+    return floats * sizeof(float);
 }
 
 static int launch_pack(const FragTable& t, hipStream_t s) {
@@ -528,14 +544,81 @@ static int make_plane_set(const fdgs_deform_params* p, float* ws, PlaneSet* ps, 
     return FDGS_OK;
 }
 
+static int launch_pack_split(const SFragTable& t, hipStream_t s) {
+    hipLaunchKernelGGL(pack_split_kernel, dim3(8, t.n), dim3(256), 0, s, t);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}
+
+// split-mode forward workspace, in floats after the plane copies:
+//   weight pieces | padded biases (b0 128, b1 5x128, b2 5x64) | feature pieces (ceil(N/32) groups x 1536 floats)
+static size_t fwd_split_bias_floats() { return DW + 5 * DW + 5 * 64; }
+static size_t fwd_split_feat_floats(int n) { return (size_t)((n + 31) / 32) * 2 * 3 * 64 * 4; }
+
+static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
+    DeformFwdSK k;
+    HexFeatSK g;
+    k.n = g.n = a->num_points;
+    float* ws = (float*)a->workspace;
+    int rc = make_plane_set(&a->p, ws, &g.ps, true, s);
+    if (rc != FDGS_OK) return rc;
+    u32x4* pk = reinterpret_cast<u32x4*>(ws + total_plane_floats(&a->p));
+    float* pb = reinterpret_cast<float*>(pk) + fwd_packed_floats(FDGS_MATMUL_SPLIT_BF16);
+    u32x4* feat = reinterpret_cast<u32x4*>(pb + fwd_split_bias_floats());
+    {
+        SFragTable t;
+        t.n = 0;
+        t.d[t.n++] = SFragDesc{a->p.w0, pk, DW, 32, 32, FRAG_FEATMAP};
+        k.pw0 = pk; pk += sfrag_vec4(DW, 32);
+        for (int h = 0; h < 5; ++h) {
+            t.d[t.n++] = SFragDesc{a->p.w1[h], pk, DW, DW, DW, 0};
+            k.pw1[h] = pk; pk += sfrag_vec4(DW, DW);
+            t.d[t.n++] = SFragDesc{a->p.w2[h], pk, h_head_dim[h], DW, DW, 0};
+            k.pw2[h] = pk; pk += sfrag_vec4(h_head_dim[h], DW);
+        }
+        rc = launch_pack_split(t, s);
+        if (rc != FDGS_OK) return rc;
+        t.n = 0;
+        t.d[t.n++] = SFragDesc{a->p.b0, reinterpret_cast<u32x4*>(pb), DW, DW, 0, FRAG_BIAS};
+        k.pb0 = pb; pb += DW;
+        for (int h = 0; h < 5; ++h) {
+            t.d[t.n++] = SFragDesc{a->p.b1[h], reinterpret_cast<u32x4*>(pb), DW, DW, 0, FRAG_BIAS};
+            k.pb1[h] = pb; pb += DW;
+            t.d[t.n++] = SFragDesc{a->p.b2[h], reinterpret_cast<u32x4*>(pb), h_head_dim[h], 64, 0, FRAG_BIAS};
+            k.pb2[h] = pb; pb += 64;
+        }
+        rc = launch_pack_split(t, s);
+        if (rc != FDGS_OK) return rc;
+    }
+    g.aabb = a->p.aabb; g.xyz = a->xyz; g.time = a->time; g.time_scalar = a->time_scalar;
+    g.feat_split = feat; g.feat_f32 = nullptr;
+    k.feat_split = feat;
+    k.in[0] = a->xyz; k.in[1] = a->scales; k.in[2] = a->rotations; k.in[3] = a->opacity; k.in[4] = a->shs;
+    k.out[0] = a->out_xyz; k.out[1] = a->out_scales; k.out[2] = a->out_rotations; k.out[3] = a->out_opacity;
+    k.out[4] = a->out_shs;
+    for (int h = 0; h < 5; ++h) { k.w2[h] = a->p.w2[h]; k.b2[h] = a->p.b2[h]; }
+    k.save_hidden = a->save_hidden;
+    k.stamps = nullptr;
+#ifdef EXP_STAMP
+    k.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 20));
+#endif
+    hipLaunchKernelGGL(hexplane_features_split_kernel, dim3((a->num_points + 127) / 128), dim3(256), 0, s, g);
+    FDGS_CHECK_LAUNCH();
+    const int blocks = (a->num_points + 32 * SCB - 1) / (32 * SCB);
+    hipLaunchKernelGGL(deform_fwd_split_kernel, dim3(blocks), dim3(64), 0, s, k);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}
+
 extern "C" int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream) {
     if (!a || a->num_points < 0 || !params_ok(&a->p)) return FDGS_EINVAL;
     if (a->num_points == 0) return FDGS_OK;
     if (!a->xyz || !a->scales || !a->rotations || !a->opacity || !a->shs || !a->out_xyz || !a->out_scales ||
         !a->out_rotations || !a->out_opacity || !a->out_shs || !a->workspace)
         return FDGS_EINVAL;
-    if (a->workspace_bytes < fdgs_deform_fwd_workspace_bytes(&a->p)) return FDGS_EWORKSPACE;
+    if (a->workspace_bytes < fdgs_deform_fwd_workspace_bytes(&a->p, a->num_points)) return FDGS_EWORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (a->p.matmul == FDGS_MATMUL_SPLIT_BF16) return deform_fwd_split(a, s);
     DeformFwdK k;
     k.n = a->num_points;
     float* ws = (float*)a->workspace;

@@ -1,0 +1,480 @@
+// Split-operand matrix products for the deformation MLP (included by deform.hip).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the rate of v_mfma_f32_32x32x16_bf16.
+// An fp32 value x is written EXACTLY as the sum of three bf16 numbers
+//     x = h + m + l,  h = top 8 significant bits, m = next 8, l = last 8
+// (truncation: h = bits & 0xffff0000, m likewise of the exact remainder x - h, ...).
+// A product x*y is then the sum of nine exact bf16 x bf16 products; the six with
+// weight >= 2^-16 (hh, hm, mh, hl, lh, mm) are issued as six bf16 MFMAs that
+// accumulate in fp32, the three dropped ones (ml, lm, ll) are below 2^-23 |xy|,
+// i.e. under the rounding error of a single fp32 multiply.  Six bf16 MFMAs of
+// K = 16 cost 192 cycles per SIMD against 512 for the eight fp32 MFMAs they replace.
+//
+// Orientation is the one of the fp32 kernels: activations transposed in the
+// accumulator layout (register r of a 32-row block holds feature row(r,h), lane
+// c = point).  For the bf16 instruction lane (c, g = lane>>5) supplies, as B
+// operand, eight K values: accumulator registers 8*jj .. 8*jj+7 of a block are
+// exactly such a group, so K chunk j = 2*block + jj carries the features
+//     kidx(j, g, e) = 16 j + 8 (e>>2) + 4 g + (e&3),   e = 0..7
+// and the weights are packed to that order (three 1-KiB pieces per fragment).
+#pragma once
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define BMFMA(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+struct Split3 { u32x4 h, m, l; };        // eight fp32 values as three bf16x8 operands
+
+// bf16 pair: low half = top 16 bits of lo, high half = top 16 bits of hi
+__device__ __forceinline__ unsigned top16_pair(float lo, float hi) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ float below_top16(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+template <bool RELU>
+__device__ __forceinline__ Split3 split8(const float* v) {
+    float x[8], r1[8], r2[8];
+    Split3 s;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = RELU ? fmaxf(v[e], 0.0f) : v[e];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.h[i] = top16_pair(x[2 * i], x[2 * i + 1]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r1[e] = below_top16(x[e]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.m[i] = top16_pair(r1[2 * i], r1[2 * i + 1]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r2[e] = below_top16(r1[e]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s.l[i] = top16_pair(r2[2 * i], r2[2 * i + 1]);
+    return s;
+}
+
+// eight consecutive registers of an accumulator block
+template <bool RELU>
+__device__ __forceinline__ Split3 split_acc(const floatx16& a, int jj) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = a[8 * jj + e];
+    return split8<RELU>(v);
+}
+// same, but the split cannot be scheduled before this point of the program: pure arithmetic is otherwise
+// free to move across sched_barrier, and the compiler gathers all splits of a layer in front of its first MFMA
+template <bool RELU>
+__device__ __forceinline__ Split3 split_acc_here(const floatx16& a, int jj) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = a[8 * jj + e];
+        asm volatile("" : "+v"(v[e]));
+    }
+    return split8<RELU>(v);
+}
+
+// c += a * b, smallest terms first
+__device__ __forceinline__ floatx16 mma_split(const Split3& a, const Split3& b, floatx16 c) {
+    c = BMFMA(a.m, b.m, c);
+    c = BMFMA(a.l, b.h, c);
+    c = BMFMA(a.h, b.l, c);
+    c = BMFMA(a.m, b.h, c);
+    c = BMFMA(a.h, b.m, c);
+    c = BMFMA(a.h, b.h, c);
+    return c;
+}
+
+// ---------------------------------------------------------------------------
+// Weight fragments, split form: for row block ib and K chunk j three u32x4 per
+// lane (pieces h, m, l), lane (c, g) holding element(32 ib + c, kidx(j, g, e)).
+// ---------------------------------------------------------------------------
+#define FRAG_BIAS 8          // not a matrix: a bias vector, copied and zero-padded
+struct SFragDesc { const float* src; u32x4* dst; int I; int K; int ld; int mode; };
+struct SFragTable { SFragDesc d[FRAG_MAX]; int n; };
+
+__host__ __device__ __forceinline__ int sfrag_vec4(int I, int K) { return ((I + 31) / 32) * ((K + 15) / 16) * 3 * 64; }
+
+__global__ void __launch_bounds__(256)
+pack_split_kernel(SFragTable t) {
+    SFragDesc d = t.d[0];
+#pragma unroll
+    for (int i = 1; i < FRAG_MAX; ++i)
+        if ((int)blockIdx.y == i) d = t.d[i];
+    if ((int)blockIdx.y >= t.n) return;
+    if (d.mode & FRAG_BIAS) {            // plain copy of I floats, zero-padded to K
+        float* dst = reinterpret_cast<float*>(d.dst);
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < d.K; idx += gridDim.x * blockDim.x)
+            dst[idx] = idx < d.I ? d.src[idx] : 0.0f;
+        return;
+    }
+    const int J = (d.K + 15) / 16, IB = (d.I + 31) / 32;
+    const int total = IB * J * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int l = idx & 63, j = (idx >> 6) % J, ib = (idx >> 6) / J;
+        const int c = l & 31, g = l >> 5;
+        const int i = 32 * ib + c;
+        const int col = (d.mode & FRAG_PERMROWS) ? (16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)) : i;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int kk = (d.mode & FRAG_FEATMAP) ? (16 * g + 8 * j + e) : (16 * j + 8 * (e >> 2) + 4 * g + (e & 3));
+            float x = 0.0f;
+            if (i < d.I && kk < d.K)
+                x = (d.mode & FRAG_TRANSPOSE) ? d.src[(size_t)kk * d.ld + col] : d.src[(size_t)col * d.ld + kk];
+            v[e] = x;
+        }
+        const Split3 s = split8<false>(v);
+        u32x4* q = d.dst + (size_t)((ib * J + j) * 3) * 64 + l;
+        q[0] = s.h; q[64] = s.m; q[128] = s.l;
+    }
+}
+
+__device__ __forceinline__ Split3 sfrag_load(const u32x4* packed, int ib, int J, int j, int lane) {
+    const u32x4* q = packed + (size_t)((ib * J + j) * 3) * 64 + lane;
+    Split3 s;
+    s.h = q[0]; s.m = q[64]; s.l = q[128];
+    return s;
+}
+
+#ifndef SCB
+#define SCB 2                            // column blocks (32 points each) per wave
+#endif
+
+#define SGB_MFMA 0x008
+#define SGB_VALU 0x002
+// scheduling hint for the block just written: n times (one MFMA, then v vector instructions)
+#define INTERLEAVE(n, v)                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {                      \
+        __builtin_amdgcn_sched_group_barrier(SGB_MFMA, 1, 0);                 \
+        __builtin_amdgcn_sched_group_barrier(SGB_VALU, (v), 0);               \
+    }
+
+// acc[cb][nb] += W[32 nb ..][:] * relu?(X[cb]) for all four row blocks of a 128x128 layer.  X is in accumulator
+// form; K chunk j+1 is split (pure VALU work) while the 48 MFMAs of chunk j run.
+template <bool RELU>
+__device__ __forceinline__ void split_layer128x4(const u32x4* packed, int lane, const floatx16 (*x)[4],
+                                                 floatx16 (*acc)[4]) {
+    // weight fragments in the order t = 4 j + nb, requested two fragments (24 MFMAs) ahead of their use
+    Split3 f[3], xs[2][SCB];
+    f[0] = sfrag_load(packed, 0, 8, 0, lane);
+    f[1] = sfrag_load(packed, 1, 8, 0, lane);
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb) xs[0][cb] = split_acc<RELU>(x[cb][0], 0);
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const int j = t >> 2, nb = t & 3;
+        if (t + 2 < 32) f[(t + 2) % 3] = sfrag_load(packed, (t + 2) & 3, 8, (t + 2) >> 2, lane);
+        if (j + 1 < 8 && nb < SCB) xs[(j + 1) & 1][nb] = split_acc_here<RELU>(x[nb][(j + 1) >> 1], (j + 1) & 1);
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb) acc[cb][nb] = mma_split(f[t % 3], xs[j & 1][cb], acc[cb][nb]);
+        INTERLEAVE(6 * SCB, 5)
+        __builtin_amdgcn_sched_barrier(0);   // keeps the prefetch distance (bounds the live registers)
+    }
+}
+
+// same with X already split (K chunks xs[cb][j]): no vector work at all besides the fragment loads
+__device__ __forceinline__ void split_layer128x4_pre(const u32x4* packed, int lane, const Split3 (*xs)[8],
+                                                     floatx16 (*acc)[4]) {
+    Split3 f[3];
+    f[0] = sfrag_load(packed, 0, 8, 0, lane);
+    f[1] = sfrag_load(packed, 1, 8, 0, lane);
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const int j = t >> 2, nb = t & 3;
+        if (t + 2 < 32) f[(t + 2) % 3] = sfrag_load(packed, (t + 2) & 3, 8, (t + 2) >> 2, lane);
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb) acc[cb][nb] = mma_split(f[t % 3], xs[cb][j], acc[cb][nb]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// acc[cb][ob] += W[32 ob ..][:] * relu?(X[cb]) for the first NOB row blocks, same pipelining
+template <bool RELU, int NOB>
+__device__ __forceinline__ void split_layer128_acc(const u32x4* packed, int lane, const floatx16 (*x)[4],
+                                                   floatx16 (*acc)[NOB]) {
+    // fragments in the order t = NOB j + ob
+    Split3 f[3], xs[2][SCB];
+    f[0] = sfrag_load(packed, 0, 8, 0, lane);
+    f[1] = sfrag_load(packed, 1 % NOB, 8, 1 / NOB, lane);
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb) xs[0][cb] = split_acc<RELU>(x[cb][0], 0);
+#pragma unroll
+    for (int t = 0; t < 8 * NOB; ++t) {
+        const int j = t / NOB, ob = t % NOB;
+        if (t + 2 < 8 * NOB) f[(t + 2) % 3] = sfrag_load(packed, (t + 2) % NOB, 8, (t + 2) / NOB, lane);
+        if (j + 1 < 8) {
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb)
+                if ((cb * NOB) / SCB == ob)      // spread the splits of chunk j+1 over the NOB steps of chunk j
+                    xs[(j + 1) & 1][cb] = split_acc_here<RELU>(x[cb][(j + 1) >> 1], (j + 1) & 1);
+        }
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb) acc[cb][ob] = mma_split(f[t % 3], xs[j & 1][cb], acc[cb][ob]);
+        INTERLEAVE(6 * SCB, NOB == 1 ? 10 : 5)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Output layer of a head with k <= 4 rows as plain fp32 dot products on the vector ALU: lane (c, h) holds 64 of
+// the 128 features of its point, the two lane halves are summed with one cross-lane add per output.  Cheaper
+// than a 32-row matrix block of which at most four rows are used.  w2 is the [k,128] weight in LDS (the
+// rows are re-read by every point tile; from LDS their latency is short enough not to need a prefetch).
+__device__ __forceinline__ void small_head(const float* w2, int k, int h, floatx16 (*x)[4], float (*res)[4]) {
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[cb][nb][r] = fmaxf(x[cb][nb][r], 0.0f);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float s[SCB];
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb) s[cb] = 0.0f;
+        if (o < k) {
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w = *reinterpret_cast<const float4*>(w2 + o * DW + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+                    for (int cb = 0; cb < SCB; ++cb) {
+                        s[cb] = fmaf(x[cb][nb][4 * q], w.x, s[cb]);
+                        s[cb] = fmaf(x[cb][nb][4 * q + 1], w.y, s[cb]);
+                        s[cb] = fmaf(x[cb][nb][4 * q + 2], w.z, s[cb]);
+                        s[cb] = fmaf(x[cb][nb][4 * q + 3], w.w, s[cb]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb) res[cb][o] = s[cb] + __shfl_xor(s[cb], 32);
+    }
+}
+
+// padded bias vector -> accumulator block nb (register 4q+i of lane half h is row 32 nb + 8 q + 4 h + i)
+__device__ __forceinline__ floatx16 bias_block(const float* __restrict__ padded, int nb, int h) {
+    floatx16 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(padded + 32 * nb + 8 * q + 4 * h);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Forward, kernel 1: HexPlane features at full occupancy.  Lane (c, h) of a wave
+// interpolates level h for point c of a 32-point group and writes its 16
+// features already split, in the B-operand order of the first Linear
+// (group G, chunk j, piece: 64 lanes x 16 bytes contiguous).
+// ---------------------------------------------------------------------------
+struct HexFeatSK {
+    int n;
+    PlaneSet ps;
+    const float* aabb;
+    const float* xyz; const float* time; float time_scalar;
+    u32x4* feat_split;                   // [ceil(n/32)][2][3][64]
+    float* feat_f32;                     // optional [n,32]
+};
+
+__global__ void __launch_bounds__(256)
+hexplane_features_split_kernel(HexFeatSK a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int G = blockIdx.x * 4 + wave;
+    if (G * 32 >= a.n) return;
+    const int p = G * 32 + c;
+    const int pc = min(p, a.n - 1);
+    float co[4], sc3[3], feat[DF];
+    point_coords(a.xyz, a.aabb, a.time, a.time_scalar, pc, co, sc3);
+    level_features(a.ps, h, co, feat, nullptr);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const Split3 s = split8<false>(feat + 8 * j);
+        u32x4* q = a.feat_split + (size_t)((G * 2 + j) * 3) * 64 + lane;
+        q[0] = s.h; q[64] = s.m; q[128] = s.l;
+    }
+    if (a.feat_f32 && p < a.n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(a.feat_f32 + (size_t)p * 32 + 16 * h + 4 * q) =
+                make_float4(feat[4 * q], feat[4 * q + 1], feat[4 * q + 2], feat[4 * q + 3]);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Forward, kernel 2: the MLP.  One wave = 64 points (two column blocks), whole
+// register file, no LDS.
+// ---------------------------------------------------------------------------
+struct DeformFwdSK {
+    int n;
+    const u32x4* feat_split;
+    const u32x4* pw0; const float* pb0;              // packed first Linear, padded bias
+    const u32x4* pw1[5]; const float* pb1[5]; const u32x4* pw2[5]; const float* pb2[5];
+    const float* w2[5]; const float* b2[5];          // unpacked output layers (used for the heads with k <= 4)
+    const float* in[5];                              // residual inputs: xyz, scales, rotations, opacity, shs
+    float* out[5];
+    float* save_hidden;                              // optional [n,128] (consumed by the fp32 backward)
+    unsigned long long* stamps;                      // EXP_STAMP builds only
+};
+
+// hidden^T = W0 f^T + b0 for the SCB point groups of this wave
+__device__ __forceinline__ void split_first_linear(const u32x4* feat_split, const u32x4* pw0, const float* pb0,
+                                                   int group0, int ngroups, int lane, int h, floatx16 (*hid)[4]) {
+    Split3 fs[SCB][2];
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb) {
+        const int G = min(group0 + cb, ngroups - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fs[cb][j] = sfrag_load(feat_split, G, 2, j, lane);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const floatx16 b = bias_block(pb0, nb, h);
+        const Split3 w_0 = sfrag_load(pw0, nb, 2, 0, lane), w_1 = sfrag_load(pw0, nb, 2, 1, lane);
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb) {
+            hid[cb][nb] = mma_split(w_0, fs[cb][0], b);
+            hid[cb][nb] = mma_split(w_1, fs[cb][1], hid[cb][nb]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64, SCB == 1 ? 2 : 1)
+deform_fwd_split_kernel(DeformFwdSK a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 31, h = lane >> 5;
+    const int base = blockIdx.x * (32 * SCB);
+
+#ifdef EXP_STAMP
+    unsigned long long stamp[8];
+    int ns = 0;
+#define STAMP() stamp[ns++] = __builtin_amdgcn_s_memtime()
+#define STAMPH(i) if (head == 1) stamp[i] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP()
+#define STAMPH(i)
+#endif
+    // output layers of the four small heads (3+3+4+1 rows of 128) staged in LDS, one row group per head
+    __shared__ float w2s[4][4 * DW];
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        const int kk = head_dim(hd);
+        const float* src = sel5(a.w2, hd);
+        for (int i = lane; i < kk * (DW / 4); i += 64)
+            reinterpret_cast<float4*>(w2s[hd])[i] = reinterpret_cast<const float4*>(src)[i];
+    }
+    __syncthreads();
+    STAMP();
+    floatx16 hid[SCB][4];
+    split_first_linear(a.feat_split, a.pw0, a.pb0, blockIdx.x * SCB, (a.n + 31) / 32, lane, h, hid);
+    STAMP();
+    if (a.save_hidden) {
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb) {
+            const int p = base + 32 * cb + c;
+            if (p < a.n) {
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(a.save_hidden + (size_t)p * DW + 32 * nb + 8 * q + 4 * h) =
+                            make_float4(hid[cb][nb][4 * q], hid[cb][nb][4 * q + 1], hid[cb][nb][4 * q + 2],
+                                        hid[cb][nb][4 * q + 3]);
+            }
+        }
+    }
+#if 1
+    Split3 hs[SCB][8];                   // relu(hidden) split once, shared by the five heads
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hs[cb][j] = split_acc<true>(hid[cb][j >> 1], j & 1);
+#endif
+    STAMP();
+    for (int head = 0; head < 5; ++head) {
+        const int k = head_dim(head);
+        const u32x4* pw1 = sel5(a.pw1, head); const float* pb1 = sel5(a.pb1, head);
+        const u32x4* pw2 = sel5(a.pw2, head); const float* pb2 = sel5(a.pb2, head);
+        const float* __restrict__ b2 = sel5(a.b2, head);
+        const float* __restrict__ in = sel5(a.in, head); float* __restrict__ out = sel5(a.out, head);
+        floatx16 h1[SCB][4];
+        STAMPH(3);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const floatx16 b = bias_block(pb1, nb, h);
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb) h1[cb][nb] = b;
+        }
+        STAMPH(4);
+#if 1
+        split_layer128x4_pre(pw1, lane, hs, h1);
+#else
+        split_layer128x4<true>(pw1, lane, hid, h1);
+#endif
+        STAMPH(5);
+        if (k <= 4) {
+            float iv[SCB][4], res[SCB][4];
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb) {
+                const int p = min(base + 32 * cb + c, a.n - 1);
+#pragma unroll
+                for (int o = 0; o < 4; ++o) iv[cb][o] = o < k ? in[(size_t)p * k + o] + b2[o] : 0.0f;
+            }
+            small_head(w2s[head], k, h, h1, res);
+            STAMPH(6);
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb) {
+                const int p = base + 32 * cb + c;
+                if (p < a.n && h == 0) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        if (o < k) out[(size_t)p * k + o] = iv[cb][o] + res[cb][o];
+                }
+            }
+        } else {                          // shs: 48 rows = two row blocks sharing the splits of h1
+            float4 iv[SCB][2][4];
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb) {
+                const int p = min(base + 32 * cb + c, a.n - 1);
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = 32 * ob + 8 * q + 4 * h;
+                        iv[cb][ob][q] = row < k ? *reinterpret_cast<const float4*>(in + (size_t)p * k + row)
+                                                : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
+            }
+            floatx16 o[SCB][2];
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob) {
+                const floatx16 b = bias_block(pb2, ob, h);
+#pragma unroll
+                for (int cb = 0; cb < SCB; ++cb) o[cb][ob] = b;
+            }
+            split_layer128_acc<true, 2>(pw2, lane, h1, o);
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb) {
+                const int p = base + 32 * cb + c;
+                if (p >= a.n) continue;
+#pragma unroll
+                for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = 32 * ob + 8 * q + 4 * h;
+                        if (row < k)
+                            *reinterpret_cast<float4*>(out + (size_t)p * k + row) =
+                                make_float4(iv[cb][ob][q].x + o[cb][ob][4 * q], iv[cb][ob][q].y + o[cb][ob][4 * q + 1],
+                                            iv[cb][ob][q].z + o[cb][ob][4 * q + 2], iv[cb][ob][q].w + o[cb][ob][4 * q + 3]);
+                    }
+            }
+        }
+    }
+#ifdef EXP_STAMP
+    stamp[7] = __builtin_amdgcn_s_memtime();
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i)
+            a.stamps[(size_t)blockIdx.x * 8 + i] = stamp[i];
+#endif
+}

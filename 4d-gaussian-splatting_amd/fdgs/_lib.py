@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdgs.so")
+LIB_PATH = os.environ.get("FDGS_LIBRARY") or os.path.join(_HERE, "libfdgs.so")   # override: a build of the same ABI
 
 MAX_LEVELS = 4
 GEOM_FLOATS = 12
@@ -66,7 +66,10 @@ class PreprocessBwdArgs(C.Structure):
 class DeformParams(C.Structure):
     _fields_ = [("num_levels", c_i32), ("res", (c_i32 * 4) * MAX_LEVELS), ("aabb", c_p),
                 ("planes", (c_p * 6) * MAX_LEVELS), ("w0", c_p), ("b0", c_p),
-                ("w1", c_p * 5), ("b1", c_p * 5), ("w2", c_p * 5), ("b2", c_p * 5)]
+                ("w1", c_p * 5), ("b1", c_p * 5), ("w2", c_p * 5), ("b2", c_p * 5), ("matmul", c_i32)]
+
+
+MATMUL_F32, MATMUL_SPLIT_BF16 = 0, 1
 
 
 class DeformParamGrads(C.Structure):
@@ -100,13 +103,13 @@ SYMBOLS = {
     "fdgs_raster_blend_fwd": (C.c_int, [C.POINTER(BlendFwdArgs), c_p]),
     "fdgs_raster_blend_bwd": (C.c_int, [C.POINTER(BlendBwdArgs), c_p]),
     "fdgs_raster_preprocess_bwd": (C.c_int, [C.POINTER(PreprocessBwdArgs), c_p]),
-    "fdgs_deform_fwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams)]),
+    "fdgs_deform_fwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
     "fdgs_deform_fwd": (C.c_int, [C.POINTER(DeformFwdArgs), c_p]),
     "fdgs_deform_bwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def _load():

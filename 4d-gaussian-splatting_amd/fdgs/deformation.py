@@ -17,6 +17,8 @@ unchanged.
 import ctypes as C
 import itertools
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -98,6 +100,11 @@ class DeformationNet(nn.Module):
         return [p for n, p in self.named_parameters() if "grid" in n]
 
 
+# how the library forms the fp32 matrix products: "f32" (fp32 MFMA) or "split" (exact three-way bf16 split of
+# both operands, six bf16 MFMAs per product, fp32 accumulation); see FDGS_MATMUL_* in include/fdgs.h
+MATMUL = {"f32": _lib.MATMUL_F32, "split": _lib.MATMUL_SPLIT_BF16}[os.environ.get("FDGS_DEFORM_MATMUL", "f32")]
+
+
 def _fill_params(net, grads=None):
     """fdgs_deform_params (or the gradient twin) from the module's tensors."""
     grid = net.grid
@@ -109,6 +116,7 @@ def _fill_params(net, grads=None):
             for k in range(4):
                 P.res[l][k] = int(reso[k])
         P.aabb = ptr(grid.aabb.detach())
+        P.matmul = MATMUL
     for l, gp in enumerate(grid.grids):
         for ci in range(6):
             P.planes[l][ci] = ptr(src(gp[ci]))
@@ -151,7 +159,7 @@ class _DeformFunction(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if need_grad else None
         P = _fill_params(net)
-        ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P))
+        ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), time_scalar,
                                ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(outs[4]), ptr(hidden),

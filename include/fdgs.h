@@ -178,6 +178,14 @@ int fdgs_raster_preprocess_bwd(const fdgs_preprocess_bwd_args* a, void* stream);
 #define FDGS_DEFORM_FEAT 16          /* channels per plane (dynerf.yaml:98)         */
 #define FDGS_DEFORM_OUT 59           /* 3 + 3 + 4 + 1 + 48 head outputs             */
 
+/* Both settings take and return fp32 and accumulate in fp32.
+ *   F32        v_mfma_f32_32x32x2_f32 (fp32 FMA chain).
+ *   SPLIT_BF16 every operand is written exactly as the sum of three bf16 numbers (8+8+8 significant bits) and a
+ *              product is the sum of the six bf16 x bf16 MFMA terms of weight >= 2^-16; the dropped terms are below
+ *              2^-23 of the product, under one fp32 rounding.  2.7x fewer matrix-core cycles. */
+#define FDGS_MATMUL_F32 0
+#define FDGS_MATMUL_SPLIT_BF16 1
+
 typedef struct {
     int32_t num_levels;                              /* len(multires)               */
     int32_t res[FDGS_DEFORM_MAX_LEVELS][4];          /* per level: x,y,z,t resolution */
@@ -188,6 +196,7 @@ typedef struct {
     /* heads in the order pos, scales, rotations, opacity, shs */
     const float* w1[5]; const float* b1[5];          /* <head>_deform.1: [128,128],[128] */
     const float* w2[5]; const float* b2[5];          /* <head>_deform.3: [k,128],[k], k = 3,3,4,1,48 */
+    int32_t matmul;                                  /* FDGS_MATMUL_*: how the fp32 matrix products are formed */
 } fdgs_deform_params;
 
 typedef struct {                                     /* gradient buffers, same shapes; accumulated INTO (+=) */
@@ -212,11 +221,11 @@ typedef struct {
     /* saved for backward (may be NULL when no gradient is needed):
      *   hidden [N,128], the pre-activation output of feature_out                   */
     float* save_hidden;
-    void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p) bytes   */
+    void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
 } fdgs_deform_fwd_args;
 
-size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p);
+size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points);
 int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream);
 
 typedef struct {
