@@ -494,7 +494,9 @@ static size_t fwd_packed_floats(int matmul) {
     for (int h = 0; h < 5; ++h) t += frag_floats(DW, DW) + frag_floats(h_head_dim[h], DW);
     return t;
 }
-static size_t bwd_packed_floats() {
+static size_t bwd_packed_floats(int matmul) {
+    if (matmul == FDGS_MATMUL_SPLIT_BF16)     // W0^T, five W1^T, W2^T of the shs head
+        return 4 * (size_t)(sfrag_vec4(32, DW) + 5 * sfrag_vec4(DW, DW) + sfrag_vec4(DW, 48));
     size_t t = frag_floats(32, DW);
     for (int h = 0; h < 5; ++h) t += 2 * frag_floats(DW, DW) + frag_floats(DW, h_head_dim[h]);
     return t;
@@ -598,6 +600,7 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     k.out[4] = a->out_shs;
     for (int h = 0; h < 5; ++h) { k.w2[h] = a->p.w2[h]; k.b2[h] = a->p.b2[h]; }
     k.save_hidden = a->save_hidden;
+    k.save_act = a->save_act;
     k.stamps = nullptr;
 #ifdef EXP_STAMP
     k.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 20));
@@ -1043,8 +1046,12 @@ extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, i
     if (!p || num_points < 0 || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS) return 0;
     const size_t pf = total_plane_floats(p);
     const size_t per_point = DW + 32 + 32;
-    return (2 * pf + bwd_packed_floats() + per_point * (size_t)num_points +
-            (size_t)1280 * bwd_chunk_points(num_points)) * sizeof(float);
+    size_t ysplit = 0;                     // pre-split operands of the weight-gradient products
+    if (p->matmul == FDGS_MATMUL_SPLIT_BF16) {
+        ysplit = (size_t)192 * (bwd_chunk_points(num_points) + 16);      // relu(hidden): 4 column blocks
+    }
+    return (2 * pf + bwd_packed_floats(p->matmul) + per_point * (size_t)num_points +
+            (size_t)1280 * bwd_chunk_points(num_points) + ysplit) * sizeof(float);
 }
 
 extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
@@ -1061,13 +1068,14 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     float* planes_cl = ws;
     float* grads_cl = ws + pf;
     float* ws_packed = grads_cl + pf;
-    float* ws_a1 = ws_packed + bwd_packed_floats();
+    float* ws_a1 = ws_packed + bwd_packed_floats(a->p.matmul);
     const size_t chunk_cap = (size_t)bwd_chunk_points(n);
     float* ws_dh1 = ws_a1 + (size_t)640 * chunk_cap;
     float* ws_dhid = ws_dh1 + (size_t)640 * chunk_cap;
     float* ws_feat = ws_dhid + (size_t)DW * n;
 
     float* ws_df = ws_feat + (size_t)32 * n;
+    float* ws_ysplit = ws_df + (size_t)32 * n;      // split mode only (sized by fdgs_deform_bwd_workspace_bytes)
 
     HexBwdK hk;
     hk.n = n;
@@ -1084,9 +1092,28 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                 off += plane_texels(&a->p, l, ci) * DF;
             }
     }
+    const bool split = a->p.matmul == FDGS_MATMUL_SPLIT_BF16;
     DeformBwdK k;
-    k.n = n;
-    {
+    DeformBwdSK ks;
+    k.n = ks.n = n;
+    if (split) {
+        if (!a->act) return FDGS_EINVAL;
+        u32x4* pk = reinterpret_cast<u32x4*>(ws_packed);
+        SFragTable t;
+        t.n = 0;
+        t.d[t.n++] = SFragDesc{a->p.w0, pk, 32, DW, 32, FRAG_TRANSPOSE | FRAG_PERMROWS};
+        ks.pw0t = pk; pk += sfrag_vec4(32, DW);
+        for (int h = 0; h < 5; ++h) {
+            t.d[t.n++] = SFragDesc{a->p.w1[h], pk, DW, DW, DW, FRAG_TRANSPOSE};
+            ks.pw1t[h] = pk; pk += sfrag_vec4(DW, DW);
+        }
+        t.d[t.n++] = SFragDesc{a->p.w2[4], pk, DW, 48, DW, FRAG_TRANSPOSE};
+        ks.pw2t_shs = pk; pk += sfrag_vec4(DW, 48);
+        rc = launch_pack_split(t, s);
+        if (rc != FDGS_OK) return rc;
+        for (int h = 0; h < 5; ++h) ks.w2[h] = a->p.w2[h];
+        ks.act = a->act;
+    } else {
         float* pk = ws_packed;
         FragTable t;
         t.n = 0;
@@ -1104,9 +1131,10 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         if (rc != FDGS_OK) return rc;
     }
     for (int h = 0; h < 5; ++h) k.b1[h] = a->p.b1[h];
-    k.hidden = a->hidden;
+    k.hidden = ks.hidden = a->hidden;
     k.g[0] = a->g_xyz; k.g[1] = a->g_scales; k.g[2] = a->g_rotations; k.g[3] = a->g_opacity; k.g[4] = a->g_shs;
-    k.ws_a1 = ws_a1; k.ws_dh1 = ws_dh1; k.ws_dhid = ws_dhid; k.ws_df = ws_df;
+    k.ws_a1 = ws_a1; k.ws_dh1 = ks.ws_dh1 = ws_dh1; k.ws_dhid = ks.ws_dhid = ws_dhid;
+    k.ws_df = ks.ws_df = ws_df;
     // Points are processed in chunks: each chunk's a1 / dh1 operands are consumed by the weight-gradient
     // products right after they are produced and the workspace holds one chunk only.
     static const int kdim[5] = {3, 3, 4, 1, 48};
@@ -1120,13 +1148,46 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         for (int h = 0; h < 5; ++h) kc.g[h] = gs[h] + (size_t)c0 * kdim[h];
         kc.ws_dhid = ws_dhid + (size_t)c0 * DW;
         kc.ws_df = ws_df + (size_t)c0 * 32;
-        hipLaunchKernelGGL(deform_bwd_points_kernel, dim3((cn + 32 * NCB - 1) / (32 * NCB)), dim3(64), 0, s, kc);
+        if (split) {
+            DeformBwdSK sc = ks;
+            sc.n = cn;
+            sc.hidden = kc.hidden;
+            sc.act = a->act + (size_t)c0 * 640;
+            for (int h = 0; h < 5; ++h) sc.g[h] = kc.g[h];
+            sc.ws_dhid = kc.ws_dhid; sc.ws_df = kc.ws_df;
+            hipLaunchKernelGGL(deform_bwd_points_split_kernel, dim3((cn + 32 * SCB - 1) / (32 * SCB)), dim3(64), 0, s, sc);
+        } else {
+            hipLaunchKernelGGL(deform_bwd_points_kernel, dim3((cn + 32 * NCB - 1) / (32 * NCB)), dim3(64), 0, s, kc);
+        }
         FDGS_CHECK_LAUNCH();
+        if (split) {
+            // dW1_h[m][n] = sum_p dh1_h[p][m] relu(hidden)[p][n]: relu(hidden) pre-split once, dh1 split on the fly
+            const int chunks = (cn + 15) / 16;
+            u32x4* y_hidden = reinterpret_cast<u32x4*>(ws_ysplit);
+            WGradPrepK pk;
+            pk.n = cn;
+            pk.d[0] = WGradPrepDesc{kc.hidden, DW, DW, 4, 1, y_hidden, nullptr};
+            for (int i = 1; i < WPREP_MAX; ++i) pk.d[i] = pk.d[0];
+            int pblocks = (chunks + 3) / 4;
+            if (pblocks > 4096) pblocks = 4096;
+            hipLaunchKernelGGL(wgrad_prep_split_kernel, dim3(pblocks, 1), dim3(256), 0, s, pk);
+            FDGS_CHECK_LAUNCH();
+            int per = (chunks + 203) / 204;     // about a thousand workgroups of four waves
+            if (per < 4) per = 4;
+            WGradSK w4;
+            w4.n = cn;
+            w4.chunks_per_block = per;
+            for (int i = 0; i < WGS_MAX; ++i) w4.d[i].C = nullptr;
+            for (int h = 0; h < 5; ++h)
+                w4.d[h] = WGradSDesc{ws_dh1 + h * DW, 640, y_hidden, a->dp.w1[h], DW, 1, DW, a->dp.b1[h]};
+            hipLaunchKernelGGL(deform_wgrad_split_kernel<4>, dim3((chunks + per - 1) / per, 5), dim3(256), 0, s, w4);
+            FDGS_CHECK_LAUNCH();
+        }
         WGradK w;
         w.n = cn;
         w.chunk = 1024;
         int nd = 0;
-        for (int h = 0; h < 5; ++h) {           // dW1_h[nn][kk] = sum_p dh1[p][nn] * relu(hidden)[p][kk]
+        for (int h = 0; h < 5 && !split; ++h) { // dW1_h[nn][kk] = sum_p dh1[p][nn] * relu(hidden)[p][kk]
             WGradDesc& d = w.d[nd++];
             d.X = ws_dh1 + h * DW; d.ldx = 640; d.M = DW;
             d.Y = kc.hidden; d.ldy = DW; d.NN = DW; d.relu_y = 1;
@@ -1135,12 +1196,14 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         for (int h = 0; h < 5; ++h) {           // dW2_h[o][kk] = sum_p g[p][o] * a1_h[p][kk]
             WGradDesc& d = w.d[nd++];
             d.X = kc.g[h]; d.ldx = kdim[h]; d.M = kdim[h];
-            d.Y = ws_a1 + h * DW; d.ldy = 640; d.NN = DW; d.relu_y = 0;
+            d.Y = (split ? a->act + (size_t)c0 * 640 : ws_a1) + h * DW; d.ldy = 640; d.NN = DW; d.relu_y = 0;
             d.C = a->dp.w2[h]; d.ldc = DW; d.db = a->dp.b2[h];
         }
-        w.d[nd].C = nullptr; w.d[nd].X = nullptr; w.d[nd].Y = nullptr; w.d[nd].db = nullptr;
-        w.d[nd].M = 0; w.d[nd].NN = 0; w.d[nd].ldx = w.d[nd].ldy = w.d[nd].ldc = 0; w.d[nd].relu_y = 0;
-        hipLaunchKernelGGL(deform_wgrad_kernel, dim3((cn + w.chunk - 1) / w.chunk, WG_MAX - 1), dim3(256), 0, s, w);
+        for (int i = nd; i < WG_MAX; ++i) {
+            w.d[i].C = nullptr; w.d[i].X = nullptr; w.d[i].Y = nullptr; w.d[i].db = nullptr;
+            w.d[i].M = 0; w.d[i].NN = 0; w.d[i].ldx = w.d[i].ldy = w.d[i].ldc = 0; w.d[i].relu_y = 0;
+        }
+        hipLaunchKernelGGL(deform_wgrad_kernel, dim3((cn + w.chunk - 1) / w.chunk, nd), dim3(256), 0, s, w);
         FDGS_CHECK_LAUNCH();
     }
 

@@ -314,7 +314,8 @@ struct DeformFwdSK {
     const float* w2[5]; const float* b2[5];          // unpacked output layers (used for the heads with k <= 4)
     const float* in[5];                              // residual inputs: xyz, scales, rotations, opacity, shs
     float* out[5];
-    float* save_hidden;                              // optional [n,128] (consumed by the fp32 backward)
+    float* save_hidden;                              // optional [n,128]: hidden, pre-activation
+    float* save_act;                                 // optional [n,640]: relu(h1) of the five heads
     unsigned long long* stamps;                      // EXP_STAMP builds only
 };
 
@@ -413,6 +414,21 @@ deform_fwd_split_kernel(DeformFwdSK a) {
         split_layer128x4<true>(pw1, lane, hid, h1);
 #endif
         STAMPH(5);
+        if (a.save_act) {
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb) {
+                const int p = base + 32 * cb + c;
+                if (p < a.n) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4*>(a.save_act + (size_t)p * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
+                                make_float4(fmaxf(h1[cb][nb][4 * q], 0.f), fmaxf(h1[cb][nb][4 * q + 1], 0.f),
+                                            fmaxf(h1[cb][nb][4 * q + 2], 0.f), fmaxf(h1[cb][nb][4 * q + 3], 0.f));
+                }
+            }
+        }
         if (k <= 4) {
             float iv[SCB][4], res[SCB][4];
 #pragma unroll
@@ -477,4 +493,311 @@ deform_fwd_split_kernel(DeformFwdSK a) {
         for (int i = 0; i < 8; ++i)
             a.stamps[(size_t)blockIdx.x * 8 + i] = stamp[i];
 #endif
+}
+
+// ===========================================================================
+// Backward, pass 1 (split form).  One wave = 64 points.  Nothing is recomputed:
+// the forward saved hidden and relu(h1) of every head.  Per head
+//     dh1 = (W2^T g) * [a1 > 0]        (vector ALU for k <= 4, MFMA for shs)
+//     dacc += W1^T dh1
+// then dhid = dacc * [hidden > 0] and dfeat = W0^T dhid.  dh1, dhid, dfeat go to
+// the workspace (point-major) for the weight-gradient products and the
+// HexPlane backward.
+// ===========================================================================
+struct DeformBwdSK {
+    int n;
+    const u32x4* pw1t[5];                        // split W1^T
+    const u32x4* pw2t_shs;                       // split W2^T of the shs head: [128 x 48]
+    const u32x4* pw0t;                           // split W0^T, rows permuted so that lane half h receives level h
+    const float* w2[5];                          // unpacked W2 (small heads)
+    const float* hidden;                         // [n,128] saved by the forward
+    const float* act;                            // [n,640] saved by the forward
+    const float* g[5];                           // output cotangents
+    float* ws_dh1; float* ws_dhid; float* ws_df;
+};
+
+__global__ void __launch_bounds__(64, 1)
+deform_bwd_points_split_kernel(DeformBwdSK a) {
+    __shared__ float w2s[4][4 * DW];
+    const int lane = threadIdx.x;
+    const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        const int kk = head_dim(hd);
+        const float* src = sel5(a.w2, hd);
+        for (int i = lane; i < kk * (DW / 4); i += 64)
+            reinterpret_cast<float4*>(w2s[hd])[i] = reinterpret_cast<const float4*>(src)[i];
+    }
+    __syncthreads();
+
+    int p[SCB], pc[SCB]; bool pvalid[SCB];
+    floatx16 dacc[SCB][4];
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb) {
+        p[cb] = blockIdx.x * (32 * SCB) + 32 * cb + c;
+        pvalid[cb] = p[cb] < a.n;
+        pc[cb] = pvalid[cb] ? p[cb] : a.n - 1;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[cb][nb][r] = 0.0f;
+    }
+    for (int head = 0; head < 5; ++head) {
+        const int k = head_dim(head);
+        const u32x4* pw1t = sel5(a.pw1t, head);
+        const float* __restrict__ g = sel5(a.g, head);
+        floatx16 t[SCB][4];      // dh1
+        // dh1 = W2^T g
+        if (k <= 4) {
+            float gv[SCB][4];
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb)
+#pragma unroll
+                for (int o = 0; o < 4; ++o) gv[cb][o] = (o < k && pvalid[cb]) ? g[(size_t)p[cb] * k + o] : 0.0f;
+            const float* w2 = w2s[head];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 acc4[SCB];
+#pragma unroll
+                    for (int cb = 0; cb < SCB; ++cb) acc4[cb] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        if (o < k) {
+                            const float4 w = *reinterpret_cast<const float4*>(w2 + o * DW + 32 * nb + 8 * q + 4 * h);
+#pragma unroll
+                            for (int cb = 0; cb < SCB; ++cb) {
+                                acc4[cb].x = fmaf(w.x, gv[cb][o], acc4[cb].x); acc4[cb].y = fmaf(w.y, gv[cb][o], acc4[cb].y);
+                                acc4[cb].z = fmaf(w.z, gv[cb][o], acc4[cb].z); acc4[cb].w = fmaf(w.w, gv[cb][o], acc4[cb].w);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int cb = 0; cb < SCB; ++cb) {
+                        t[cb][nb][4 * q] = acc4[cb].x; t[cb][nb][4 * q + 1] = acc4[cb].y;
+                        t[cb][nb][4 * q + 2] = acc4[cb].z; t[cb][nb][4 * q + 3] = acc4[cb].w;
+                    }
+                }
+        } else {
+            Split3 gsp[SCB][3];
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = g0;
+                    if (pvalid[cb]) {
+                        g0 = *reinterpret_cast<const float4*>(g + (size_t)p[cb] * 48 + 16 * j + 4 * h);
+                        g1 = *reinterpret_cast<const float4*>(g + (size_t)p[cb] * 48 + 16 * j + 8 + 4 * h);
+                    }
+                    const float v[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                    gsp[cb][j] = split8<false>(v);
+                }
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[cb][nb][r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const Split3 w = sfrag_load(a.pw2t_shs, nb, 3, j, lane);
+#pragma unroll
+                    for (int cb = 0; cb < SCB; ++cb) t[cb][nb] = mma_split(w, gsp[cb][j], t[cb][nb]);
+                }
+        }
+        // ReLU mask from the saved activation, and dh1 out
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 av = *reinterpret_cast<const float4*>(a.act + (size_t)pc[cb] * 640 + head * DW + 32 * nb + 8 * q + 4 * h);
+                    if (!(av.x > 0.0f)) t[cb][nb][4 * q] = 0.0f;
+                    if (!(av.y > 0.0f)) t[cb][nb][4 * q + 1] = 0.0f;
+                    if (!(av.z > 0.0f)) t[cb][nb][4 * q + 2] = 0.0f;
+                    if (!(av.w > 0.0f)) t[cb][nb][4 * q + 3] = 0.0f;
+#ifndef EXP_NOSTORE
+                    if (pvalid[cb])
+#else
+                    if (pvalid[cb] && a.n < 0)
+#endif
+                        *reinterpret_cast<float4*>(a.ws_dh1 + (size_t)p[cb] * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
+                            make_float4(t[cb][nb][4 * q], t[cb][nb][4 * q + 1], t[cb][nb][4 * q + 2], t[cb][nb][4 * q + 3]);
+                }
+        split_layer128x4<false>(pw1t, lane, t, dacc);
+    }
+    floatx16 df[SCB][1];
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 hv = *reinterpret_cast<const float4*>(a.hidden + (size_t)pc[cb] * DW + 32 * nb + 8 * q + 4 * h);
+                if (!(hv.x > 0.0f)) dacc[cb][nb][4 * q] = 0.0f;
+                if (!(hv.y > 0.0f)) dacc[cb][nb][4 * q + 1] = 0.0f;
+                if (!(hv.z > 0.0f)) dacc[cb][nb][4 * q + 2] = 0.0f;
+                if (!(hv.w > 0.0f)) dacc[cb][nb][4 * q + 3] = 0.0f;
+                if (pvalid[cb])
+                    *reinterpret_cast<float4*>(a.ws_dhid + (size_t)p[cb] * DW + 32 * nb + 8 * q + 4 * h) =
+                        make_float4(dacc[cb][nb][4 * q], dacc[cb][nb][4 * q + 1], dacc[cb][nb][4 * q + 2],
+                                    dacc[cb][nb][4 * q + 3]);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) df[cb][0][r] = 0.0f;
+    }
+    split_layer128_acc<false, 1>(a.pw0t, lane, dacc, df);
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb)
+        if (pvalid[cb]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(a.ws_df + (size_t)p[cb] * 32 + 16 * h + 4 * q) =
+                    make_float4(df[cb][0][4 * q], df[cb][0][4 * q + 1], df[cb][0][4 * q + 2], df[cb][0][4 * q + 3]);
+        }
+}
+
+// ===========================================================================
+// Backward, pass 2 (split form): C[m][n] += sum_p X[p][m] * relu(Y[p][n]) for the
+// 128 x 128 products (dW1 of the five heads; Y = hidden is the same for all of
+// them), db[m] += sum_p X[p][m].  The points are the MFMA K dimension: for a K
+// chunk of 16 points lane (c, g) holds the eight points pb + 8 g + e of column c.
+//   prep   relu(Y) is split once into B-operand order (chunk, column block, piece:
+//          64 lanes x 16 bytes) - every head and row block re-reads it.
+//   main   workgroup = (point range, head), wave = row block of 32: per chunk
+//          eight coalesced dword loads of X (one 128-byte row segment per lane
+//          half), one split, twelve 1-KiB piece loads, 24 MFMAs.
+// ===========================================================================
+// prep: Y[p][0..ncols) (ncols <= 32 nb) -> split pieces, order (chunk, column block, piece, lane); optionally
+// relu first; optionally the column sums of Y accumulated into colsum[0..ncols) (bias gradients)
+struct WGradPrepDesc { const float* Y; int ldy; int ncols; int nb; int relu; u32x4* out; float* colsum; };
+#define WPREP_MAX 8
+struct WGradPrepK { int n; WGradPrepDesc d[WPREP_MAX]; };
+
+__global__ void __launch_bounds__(256)
+wgrad_prep_split_kernel(WGradPrepK a) {
+    WGradPrepDesc d = a.d[0];
+#pragma unroll
+    for (int i = 1; i < WPREP_MAX; ++i)
+        if ((int)blockIdx.y == i) d = a.d[i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, g = lane >> 5;
+    const int total_chunks = (a.n + 15) / 16;
+    float csum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int chunk = blockIdx.x * 4 + wave; chunk < total_chunks; chunk += gridDim.x * 4) {
+        const int pb = chunk * 16;
+        float v[4][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int p = pb + 8 * g + e;
+            const bool ok = p < a.n;
+            const float* row = d.Y + (size_t)(ok ? p : pb) * d.ldy;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+                float x = 0.0f;
+                if (nb < d.nb) {
+                    const int col = 32 * nb + c;
+                    x = (ok && col < d.ncols) ? row[col < d.ncols ? col : 0] : 0.0f;
+                    csum[nb] += x;
+                    if (d.relu) x = fmaxf(x, 0.0f);
+                }
+                v[nb][e] = x;
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            if (nb < d.nb) {
+                const Split3 s3 = split8<false>(v[nb]);
+                u32x4* q = d.out + (size_t)((chunk * d.nb + nb) * 3) * 64 + lane;
+                q[0] = s3.h; q[64] = s3.m; q[128] = s3.l;
+            }
+        }
+    }
+    if (d.colsum) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+            if (nb < d.nb && 32 * nb + c < d.ncols) atomicAdd(d.colsum + 32 * nb + c, csum[nb]);
+    }
+}
+
+// main: C(m, n) += sum_p X[p][m] * Ysplit[p][n], m < 128 (wave = row block), n < 32 NB; element (m, n) lives at
+// C + m*sm + n*sn and only n < nvalid is written; rowsum[m] += sum_p X[p][m] if given
+struct WGradSDesc {
+    const float* X; int ldx;
+    const u32x4* ysplit;
+    float* C; int sm; int sn; int nvalid;
+    float* rowsum;
+};
+#define WGS_MAX 6
+struct WGradSK {
+    int n; int chunks_per_block;
+    WGradSDesc d[WGS_MAX];
+};
+
+template <int NB>
+__global__ void __launch_bounds__(256)
+deform_wgrad_split_kernel(WGradSK a) {
+    WGradSDesc d = a.d[0];
+#pragma unroll
+    for (int i = 1; i < WGS_MAX; ++i)
+        if ((int)blockIdx.y == i) d = a.d[i];
+    if (!d.C) return;
+    const int lane = threadIdx.x & 63, mb = threadIdx.x >> 6;
+    const int c = lane & 31, g = lane >> 5;
+    const int total_chunks = (a.n + 15) / 16;
+    const int ch_begin = blockIdx.x * a.chunks_per_block;
+    const int ch_end = min(ch_begin + a.chunks_per_block, total_chunks);
+    if (ch_begin >= ch_end) return;
+    floatx16 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+    float bsum = 0.0f;
+    const float* __restrict__ X = d.X + 32 * mb + c;
+    // one chunk ahead: raw X values and the Y pieces of the next chunk are requested before this chunk's MFMAs
+    float xv[8], xn[8];
+    Split3 ys[NB], yn[NB];
+    auto load_chunk = [&](int ch, float* xo, Split3* yo) {
+        const int pb = ch * 16;
+        if (pb + 16 <= a.n) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xo[e] = X[(size_t)(pb + 8 * g + e) * d.ldx];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int p = pb + 8 * g + e;
+                xo[e] = p < a.n ? X[(size_t)p * d.ldx] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) yo[nb] = sfrag_load(d.ysplit, ch, NB, nb, lane);
+    };
+    load_chunk(ch_begin, xv, ys);
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        if (ch + 1 < ch_end) load_chunk(ch + 1, xn, yn);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum += xv[e];
+        const Split3 xs = split8<false>(xv);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = mma_split(xs, ys[nb], acc[nb]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = xn[e];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) ys[nb] = yn[nb];
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int n = 32 * nb + c;
+        if (n < d.nvalid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                atomicAdd(d.C + (size_t)(32 * mb + drow(r, g)) * d.sm + (size_t)n * d.sn, acc[nb][r]);
+        }
+    }
+    if (d.rowsum) atomicAdd(d.rowsum + 32 * mb + c, bsum);
 }

@@ -102,7 +102,7 @@ class DeformationNet(nn.Module):
 
 # how the library forms the fp32 matrix products: "f32" (fp32 MFMA) or "split" (exact three-way bf16 split of
 # both operands, six bf16 MFMAs per product, fp32 accumulation); see FDGS_MATMUL_* in include/fdgs.h
-MATMUL = {"f32": _lib.MATMUL_F32, "split": _lib.MATMUL_SPLIT_BF16}[os.environ.get("FDGS_DEFORM_MATMUL", "f32")]
+MATMUL = {"f32": _lib.MATMUL_F32, "split": _lib.MATMUL_SPLIT_BF16}[os.environ.get("FDGS_DEFORM_MATMUL", "split")]
 
 
 def _fill_params(net, grads=None):
@@ -158,23 +158,26 @@ class _DeformFunction(torch.autograd.Function):
         outs = [torch.empty_like(t) for t in (xyz_c, sc_c, ro_c, op_c, sh_c)]
         need_grad = any(ctx.needs_input_grad)
         hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if need_grad else None
+        act = (torch.empty(N, 5 * net.W, device=dev, dtype=torch.float32)
+               if need_grad and MATMUL == _lib.MATMUL_SPLIT_BF16 else None)
         P = _fill_params(net)
         ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), time_scalar,
                                ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(outs[4]), ptr(hidden),
-                               ptr(ws), ws_bytes)
+                               ptr(act), ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_fwd", a)
         ctx.net = net
         ctx.time_scalar = time_scalar
         ctx.param_versions = [p._version for p in params]
-        ctx.save_for_backward(xyz_c, time_c, hidden, ws)
+        ctx.matmul = MATMUL
+        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_xyz, g_sc, g_ro, g_op, g_sh):
         net = ctx.net
-        xyz_c, time_c, hidden, fwd_ws = ctx.saved_tensors
+        xyz_c, time_c, hidden, fwd_ws, act = ctx.saved_tensors
         N = xyz_c.shape[0]
         dev = xyz_c.device
         c = lambda t, like: (torch.zeros_like(like) if t is None else t.to(torch.float32).contiguous())
@@ -189,6 +192,7 @@ class _DeformFunction(torch.autograd.Function):
             grads[id(p)] = flat[off:off + p.numel()].view(p.shape)
             off += p.numel()
         P = _fill_params(net)
+        P.matmul = ctx.matmul
         G = _fill_params(net, grads)
         d_xyz = torch.empty_like(xyz_c)
         # the forward's channel-last plane copies are still valid if no parameter was written since
@@ -196,7 +200,7 @@ class _DeformFunction(torch.autograd.Function):
         planes_cl = ptr(fwd_ws) if unchanged else None
         ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
+        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_bwd", a)
         pg = tuple(grads[id(p)] for p in params)

@@ -221,6 +221,9 @@ typedef struct {
     /* saved for backward (may be NULL when no gradient is needed):
      *   hidden [N,128], the pre-activation output of feature_out                   */
     float* save_hidden;
+    /*   act [N,640], relu of the five heads' first Linear: required for the backward when
+     *   p.matmul == FDGS_MATMUL_SPLIT_BF16 (that backward recomputes nothing), unused otherwise */
+    float* save_act;
     void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
 } fdgs_deform_fwd_args;
@@ -234,6 +237,7 @@ typedef struct {
     const float* xyz;
     const float* time; float time_scalar;
     const float* hidden;             /* [N,128] saved by the forward                */
+    const float* act;                /* [N,640] saved by the forward (SPLIT_BF16 only, else may be NULL) */
     const float* planes_channel_last;/* the forward's workspace (channel-last plane copies) if the parameters have
                                         not changed since, else NULL: the copies are rebuilt inside the workspace */
     /* output cotangents; the residual inputs (scales, rotations, opacity, shs)

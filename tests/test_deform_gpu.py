@@ -29,8 +29,16 @@ def _rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+@pytest.fixture(params=["split", "f32"])
+def matmul(request, monkeypatch):
+    """Both ways the library forms the fp32 matrix products (FDGS_MATMUL_* in include/fdgs.h)."""
+    from fdgs import _lib, deformation
+    monkeypatch.setattr(deformation, "MATMUL", {"f32": _lib.MATMUL_F32, "split": _lib.MATMUL_SPLIT_BF16}[request.param])
+    return request.param
+
+
 @pytest.mark.parametrize("case", list(dc.CASES))
-def test_forward_backward_vs_golden_and_oracle(case):
+def test_forward_backward_vs_golden_and_oracle(case, matmul):
     dev = torch.device("cuda:0")
     net, sd = _module(case, dev)
     gold = np.load(os.path.join(GOLD, f"deform_{case}.npz"))
@@ -52,7 +60,7 @@ def test_forward_backward_vs_golden_and_oracle(case):
         assert _rel(g.cpu(), torch.from_numpy(gold["gp_" + k])) <= GRAD_TOL, k
 
 
-def test_scalar_time_single_view_and_no_grad():
+def test_scalar_time_single_view_and_no_grad(matmul):
     """render() passes one time per view repeated N times (gaussian_renderer/__init__.py:52);
     also runs under torch.no_grad and with N not a multiple of the tile."""
     dev = torch.device("cuda:0")
@@ -67,3 +75,27 @@ def test_scalar_time_single_view_and_no_grad():
         assert float((a.cpu() - b).abs().max()) <= OUT_TOL
     one = net(xyz[:1].to(dev), sc[:1].to(dev), ro[:1].to(dev), op[:1].to(dev), sh[:1].to(dev), t[:1].to(dev))
     assert [tuple(o.shape) for o in one] == [(1, 3), (1, 3), (1, 4), (1, 1), (1, 16, 3)]
+
+
+def test_split_products_are_fp32_accurate():
+    """The split-bf16 matrix products (six exact bf16 x bf16 terms, fp32 accumulation) must be as close
+    to a float64 evaluation as the fp32-MFMA path is: the forward has no discontinuity inside the box,
+    so the two error levels are directly comparable."""
+    from fdgs import _lib, deformation
+    dev = torch.device("cuda:0")
+    net, sd = _module("dynerf", dev)
+    xyz, sc, ro, op, sh, tm = dc.make_inputs("dynerf")
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref = deform_ref.deform_forward(sd64, xyz.double(), sc.double(), ro.double(), op.double(), sh.double(), tm.double())
+    errs = {}
+    old = deformation.MATMUL
+    try:
+        for name, mode in (("f32", _lib.MATMUL_F32), ("split", _lib.MATMUL_SPLIT_BF16)):
+            deformation.MATMUL = mode
+            with torch.no_grad():
+                got = net(xyz.to(dev), sc.to(dev), ro.to(dev), op.to(dev), sh.to(dev), tm.to(dev))
+            errs[name] = max(float((a.cpu().double() - b).abs().max()) for a, b in zip(got, ref))
+    finally:
+        deformation.MATMUL = old
+    assert errs["f32"] <= 2e-6 and errs["split"] <= 2e-6, errs
+    assert errs["split"] <= 2.0 * errs["f32"] + 2e-7, errs
