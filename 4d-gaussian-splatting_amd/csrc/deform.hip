@@ -20,6 +20,8 @@
 // lookup instead of 16 strided lines), rebuilt from the parameter layout
 // [16][H][W] at the start of every call (9.5 MB, a few microseconds).
 #include "fdgs_common.h"
+#include <mutex>
+#include <cstdlib>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -558,6 +560,7 @@ static size_t fwd_split_bias_floats() { return DW + 5 * DW + 5 * 64; }
 static size_t fwd_split_feat_floats(int n) { return (size_t)((n + 31) / 32) * 2 * 3 * 64 * 4; }
 
 static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
+    if ((a->save_hidden == nullptr) != (a->save_act == nullptr)) return FDGS_EINVAL;   // both or neither
     DeformFwdSK k;
     HexFeatSK g;
     k.n = g.n = a->num_points;
@@ -608,7 +611,8 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     hipLaunchKernelGGL(hexplane_features_split_kernel, dim3((a->num_points + 127) / 128), dim3(256), 0, s, g);
     FDGS_CHECK_LAUNCH();
     const int blocks = (a->num_points + 32 * SCB - 1) / (32 * SCB);
-    hipLaunchKernelGGL(deform_fwd_split_kernel, dim3(blocks), dim3(64), 0, s, k);
+    if (a->save_hidden && a->save_act) hipLaunchKernelGGL(deform_fwd_split_kernel<true>, dim3(blocks), dim3(64), 0, s, k);
+    else hipLaunchKernelGGL(deform_fwd_split_kernel<false>, dim3(blocks), dim3(64), 0, s, k);
     FDGS_CHECK_LAUNCH();
     return FDGS_OK;
 }
@@ -1054,6 +1058,28 @@ extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, i
             (size_t)1280 * bwd_chunk_points(num_points) + ysplit) * sizeof(float);
 }
 
+// The HexPlane scatter (atomics-bound) and the weight-gradient products (matrix-core / memory-bound) only
+// depend on pass 1, not on each other: they are issued on two streams (fork after pass 1, join before
+// returning to the caller's stream order).  One helper stream and two events per device, created on first
+// use and kept for the life of the process; calls on the same device must not overlap in time.
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; bool ok; };
+static SideStream* side_stream() {
+    static SideStream table[64];
+    static bool made[64];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!made[dev]) {
+        SideStream& t = table[dev];
+        t.ok = hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess;
+        made[dev] = true;
+    }
+    return table[dev].ok ? &table[dev] : nullptr;
+}
+
 extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     if (!a || a->num_points < 0 || !params_ok(&a->p)) return FDGS_EINVAL;
     if (a->num_points == 0) return FDGS_OK;
@@ -1135,8 +1161,65 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     k.g[0] = a->g_xyz; k.g[1] = a->g_scales; k.g[2] = a->g_rotations; k.g[3] = a->g_opacity; k.g[4] = a->g_shs;
     k.ws_a1 = ws_a1; k.ws_dh1 = ks.ws_dh1 = ws_dh1; k.ws_dhid = ks.ws_dhid = ws_dhid;
     k.ws_df = ks.ws_df = ws_df;
+    // pass 1b + dW0 + plane-gradient layout change: everything downstream of dfeat; runs on stream hs
+    auto hex_tail = [&](hipStream_t hs) -> int {
+        // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
+        hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
+        hk.ws_df = ws_df; hk.ws_feat = ws_feat; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
+        hk.lds_time = (a->time == nullptr) ? 1 : 0;
+        int hex_lds_floats = 0;
+        for (int l = 0; l < 2; ++l)
+            for (int tp = 0; tp < 3; ++tp) hex_lds_floats += 2 * a->p.res[l][tp] * DF;
+        if ((size_t)hex_lds_floats * sizeof(float) > 150 * 1024) { hk.lds_time = 0; }
+        const size_t hex_lds_bytes = hk.lds_time ? (size_t)hex_lds_floats * sizeof(float) : 0;
+        if (hex_lds_bytes > 64 * 1024 &&
+            hipFuncSetAttribute((const void*)hexplane_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)hex_lds_bytes) != hipSuccess)
+            return FDGS_ELAUNCH;
+        {
+            const long long waves_needed = ((long long)2 * n + 3) / 4;
+            long long hb = (waves_needed + 3) / 4;
+            if (hb > 512) hb = 512;
+            if (hb < 1) hb = 1;
+            hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)hb), dim3(256), hex_lds_bytes, hs, hk, hex_lds_floats);
+            FDGS_CHECK_LAUNCH();
+        }
+        {                                           // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f]
+            WGradK w;
+            w.n = n;
+            w.chunk = 1024;
+            for (int i = 0; i < WG_MAX; ++i) {
+                w.d[i].C = nullptr; w.d[i].X = nullptr; w.d[i].Y = nullptr; w.d[i].db = nullptr;
+                w.d[i].M = 0; w.d[i].NN = 0; w.d[i].ldx = w.d[i].ldy = w.d[i].ldc = 0; w.d[i].relu_y = 0;
+            }
+            WGradDesc& d = w.d[0];
+            d.X = ws_dhid; d.ldx = DW; d.M = DW;
+            d.Y = ws_feat; d.ldy = 32; d.NN = 32; d.relu_y = 0;
+            d.C = a->dp.w0; d.ldc = 32; d.db = a->dp.b0;
+            hipLaunchKernelGGL(deform_wgrad_kernel, dim3((n + w.chunk - 1) / w.chunk, 1), dim3(256), 0, hs, w);
+            FDGS_CHECK_LAUNCH();
+        }
+
+        // plane gradients back to the parameter layout [16][H][W] (one launch, += into the caller's buffers)
+        {
+            PlaneTable t;
+            int max_hw = 0;
+            for (int l = 0; l < 2; ++l)
+                for (int ci = 0; ci < 6; ++ci) {
+                    const int hw = (int)plane_texels(&a->p, l, ci);
+                    t.src[6 * l + ci] = hk.gpl[l][ci];
+                    t.dst[6 * l + ci] = a->dp.planes[l][ci];
+                    t.hw[6 * l + ci] = hw;
+                    if (hw > max_hw) max_hw = hw;
+                }
+            hipLaunchKernelGGL(planes_grad_from_channel_last_kernel, dim3((max_hw + 255) / 256, 12), dim3(256), 0, hs, t);
+            FDGS_CHECK_LAUNCH();
+        }
+        return FDGS_OK;
+    };
     // Points are processed in chunks: each chunk's a1 / dh1 operands are consumed by the weight-gradient
     // products right after they are produced and the workspace holds one chunk only.
+    SideStream* side = getenv("FDGS_SINGLE_STREAM") ? nullptr : side_stream();
     static const int kdim[5] = {3, 3, 4, 1, 48};
     const float* gs[5] = {a->g_xyz, a->g_scales, a->g_rotations, a->g_opacity, a->g_shs};
     const int chunk_pts = bwd_chunk_points(n);
@@ -1160,6 +1243,16 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             hipLaunchKernelGGL(deform_bwd_points_kernel, dim3((cn + 32 * NCB - 1) / (32 * NCB)), dim3(64), 0, s, kc);
         }
         FDGS_CHECK_LAUNCH();
+        if (c0 + cn >= n) {                     // pass 1 complete: fork the HexPlane tail
+            if (side) {
+                if (hipEventRecord(side->fork, s) != hipSuccess ||
+                    hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess)
+                    return FDGS_ELAUNCH;
+                rc = hex_tail(side->stream);
+                if (rc != FDGS_OK) return rc;
+                if (hipEventRecord(side->join, side->stream) != hipSuccess) return FDGS_ELAUNCH;
+            }
+        }
         if (split) {
             // dW1_h[m][n] = sum_p dh1_h[p][m] relu(hidden)[p][n]: relu(hidden) pre-split once, dh1 split on the fly
             const int chunks = (cn + 15) / 16;
@@ -1206,58 +1299,11 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         hipLaunchKernelGGL(deform_wgrad_kernel, dim3((cn + w.chunk - 1) / w.chunk, nd), dim3(256), 0, s, w);
         FDGS_CHECK_LAUNCH();
     }
-
-    // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
-    hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
-    hk.ws_df = ws_df; hk.ws_feat = ws_feat; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
-    hk.lds_time = (a->time == nullptr) ? 1 : 0;
-    int hex_lds_floats = 0;
-    for (int l = 0; l < 2; ++l)
-        for (int tp = 0; tp < 3; ++tp) hex_lds_floats += 2 * a->p.res[l][tp] * DF;
-    if ((size_t)hex_lds_floats * sizeof(float) > 150 * 1024) { hk.lds_time = 0; }
-    const size_t hex_lds_bytes = hk.lds_time ? (size_t)hex_lds_floats * sizeof(float) : 0;
-    if (hex_lds_bytes > 64 * 1024 &&
-        hipFuncSetAttribute((const void*)hexplane_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)hex_lds_bytes) != hipSuccess)
-        return FDGS_ELAUNCH;
-    {
-        const long long waves_needed = ((long long)2 * n + 3) / 4;
-        long long hb = (waves_needed + 3) / 4;
-        if (hb > 512) hb = 512;
-        if (hb < 1) hb = 1;
-        hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)hb), dim3(256), hex_lds_bytes, s, hk, hex_lds_floats);
-        FDGS_CHECK_LAUNCH();
-    }
-    {                                           // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f]
-        WGradK w;
-        w.n = n;
-        w.chunk = 1024;
-        for (int i = 0; i < WG_MAX; ++i) {
-            w.d[i].C = nullptr; w.d[i].X = nullptr; w.d[i].Y = nullptr; w.d[i].db = nullptr;
-            w.d[i].M = 0; w.d[i].NN = 0; w.d[i].ldx = w.d[i].ldy = w.d[i].ldc = 0; w.d[i].relu_y = 0;
-        }
-        WGradDesc& d = w.d[0];
-        d.X = ws_dhid; d.ldx = DW; d.M = DW;
-        d.Y = ws_feat; d.ldy = 32; d.NN = 32; d.relu_y = 0;
-        d.C = a->dp.w0; d.ldc = 32; d.db = a->dp.b0;
-        hipLaunchKernelGGL(deform_wgrad_kernel, dim3((n + w.chunk - 1) / w.chunk, 1), dim3(256), 0, s, w);
-        FDGS_CHECK_LAUNCH();
-    }
-
-    // plane gradients back to the parameter layout [16][H][W] (one launch, += into the caller's buffers)
-    {
-        PlaneTable t;
-        int max_hw = 0;
-        for (int l = 0; l < 2; ++l)
-            for (int ci = 0; ci < 6; ++ci) {
-                const int hw = (int)plane_texels(&a->p, l, ci);
-                t.src[6 * l + ci] = hk.gpl[l][ci];
-                t.dst[6 * l + ci] = a->dp.planes[l][ci];
-                t.hw[6 * l + ci] = hw;
-                if (hw > max_hw) max_hw = hw;
-            }
-        hipLaunchKernelGGL(planes_grad_from_channel_last_kernel, dim3((max_hw + 255) / 256, 12), dim3(256), 0, s, t);
-        FDGS_CHECK_LAUNCH();
+    if (side) {                                 // join
+        if (hipStreamWaitEvent(s, side->join, 0) != hipSuccess) return FDGS_ELAUNCH;
+    } else {
+        rc = hex_tail(s);
+        if (rc != FDGS_OK) return rc;
     }
     return FDGS_OK;
 }

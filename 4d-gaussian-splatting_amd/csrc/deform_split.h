@@ -341,6 +341,8 @@ __device__ __forceinline__ void split_first_linear(const u32x4* feat_split, cons
     }
 }
 
+// SAVE: training variant, stores hidden and relu(h1) for the backward
+template <bool SAVE>
 __global__ void __launch_bounds__(64, SCB == 1 ? 2 : 1)
 deform_fwd_split_kernel(DeformFwdSK a) {
     const int lane = threadIdx.x;
@@ -370,7 +372,7 @@ deform_fwd_split_kernel(DeformFwdSK a) {
     floatx16 hid[SCB][4];
     split_first_linear(a.feat_split, a.pw0, a.pb0, blockIdx.x * SCB, (a.n + 31) / 32, lane, h, hid);
     STAMP();
-    if (a.save_hidden) {
+    if (SAVE) {
 #pragma unroll
         for (int cb = 0; cb < SCB; ++cb) {
             const int p = base + 32 * cb + c;
@@ -414,7 +416,7 @@ deform_fwd_split_kernel(DeformFwdSK a) {
         split_layer128x4<true>(pw1, lane, hid, h1);
 #endif
         STAMPH(5);
-        if (a.save_act) {
+        if (SAVE) {
 #pragma unroll
             for (int cb = 0; cb < SCB; ++cb) {
                 const int p = base + 32 * cb + c;

@@ -142,7 +142,7 @@ def _trainable(net):
 
 class _DeformFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, xyz, scales, rotations, opacity, shs, time, *params):
+    def forward(ctx, net, grad_mode, xyz, scales, rotations, opacity, shs, time, *params):
         _lib.require_gpu(xyz, scales, rotations, opacity, shs, *params)
         N = xyz.shape[0]
         dev = xyz.device
@@ -156,7 +156,9 @@ class _DeformFunction(torch.autograd.Function):
             if time_c.numel() != N:
                 raise ValueError("time must have one entry per point")
         outs = [torch.empty_like(t) for t in (xyz_c, sc_c, ro_c, op_c, sh_c)]
-        need_grad = any(ctx.needs_input_grad)
+        # needs_input_grad is also set under torch.no_grad(); the caller's grad mode decides whether
+        # the activations are saved (0.92 GB at 300k points)
+        need_grad = grad_mode and any(ctx.needs_input_grad)
         hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if need_grad else None
         act = (torch.empty(N, 5 * net.W, device=dev, dtype=torch.float32)
                if need_grad and MATMUL == _lib.MATMUL_SPLIT_BF16 else None)
@@ -204,8 +206,8 @@ class _DeformFunction(torch.autograd.Function):
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_bwd", a)
         pg = tuple(grads[id(p)] for p in params)
-        # net, xyz, scales, rotations, opacity, shs, time, *params
-        return (None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + pg
+        # net, grad_mode, xyz, scales, rotations, opacity, shs, time, *params
+        return (None, None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + pg
 
 
 class DeformationFields(nn.Module):
@@ -250,7 +252,8 @@ class DeformationFields(nn.Module):
 
     def forward_dynamic(self, point, scales=None, rotations=None, opacity=None, shs=None, time=None):
         net = self.deformation_net
-        return _DeformFunction.apply(net, point, scales, rotations, opacity, shs, time, *_trainable(net))
+        return _DeformFunction.apply(net, torch.is_grad_enabled(), point, scales, rotations, opacity, shs, time,
+                                     *_trainable(net))
 
     def get_mlp_parameters(self):
         return self.deformation_net.get_mlp_parameters()
