@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--height", type=int, default=1014)
     ap.add_argument("--render-frames", type=int, default=60, help="frames of the inference-only FPS leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32-mfma-steps", type=int, default=10,
+                    help="steps of the extra leg that forms the deformation matrix products with fp32 MFMA (0 = skip)")
     ap.add_argument("--cpu-tile-stride", type=int, default=48, help="cpu baseline blends every k-th tile")
     return ap.parse_args()
 
@@ -137,6 +139,8 @@ def main():
     from fdgs.renderer import render
     from fdgs.train_step import TrainStep
 
+    from fdgs import deformation as _deformation
+    split_is_default = _deformation.MATMUL == _lib.MATMUL_SPLIT_BF16
     g, net, deforms, cams, bg = build_scene(args, dev)
     step = TrainStep(g, deforms, bg)
     train_cams = cams[:20]
@@ -165,6 +169,28 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # extra leg, not the headline: same step with the deformation matrix products on v_mfma_f32_32x32x2_f32
+    # instead of the exact three-way bf16 split (both take, accumulate and return fp32)
+    fp32_mfma = None
+    if args.fp32_mfma_steps > 0 and split_is_default:
+        from fdgs import deformation
+        split_mode = deformation.MATMUL
+        deformation.MATMUL = _lib.MATMUL_F32
+        for i in range(2):
+            step(batch(i))
+        sync()
+        t2 = time.perf_counter()
+        for i in range(args.fp32_mfma_steps):
+            step(batch(2 + i))
+        sync()
+        dt2 = time.perf_counter() - t2
+        deformation.MATMUL = split_mode
+        if world > 1:
+            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        fp32_mfma = world * args.fp32_mfma_steps / dt2
 
     # inference-only leg: deformation + forward rasterizer, frames strided over ranks, no collective
     fps = None
@@ -212,7 +238,11 @@ def main():
                                    "per GPU (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + Adam)",
                        "gaussians": args.gaussians, "image": [args.width, args.height], "sh_degree": 3,
                        "global_batch_views": world, "views_per_gpu": 1, "tile_list_entries": R,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}",
+                       "deform_matmul": ("fp32 in / fp32 accumulate / fp32 out; products formed from an exact "
+                                         "three-way bf16 split of both operands, six bf16 MFMA terms (error below "
+                                         "one fp32 rounding per product)" if split_is_default else "fp32 MFMA")},
+            "train_it_s_fp32_mfma": fp32_mfma,
             "render_fps": fps,
             "kernel_ms": per_call,
             "roofline": {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
