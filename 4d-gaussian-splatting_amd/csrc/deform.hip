@@ -560,7 +560,8 @@ static size_t fwd_split_bias_floats() { return DW + 5 * DW + 5 * 64; }
 static size_t fwd_split_feat_floats(int n) { return (size_t)((n + 31) / 32) * 2 * 3 * 64 * 4; }
 
 static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
-    if ((a->save_hidden == nullptr) != (a->save_act == nullptr)) return FDGS_EINVAL;   // both or neither
+    if ((a->save_hidden == nullptr) != (a->save_act == nullptr) || (a->save_act == nullptr) != (a->save_mask == nullptr))
+        return FDGS_EINVAL;                                                        // all three or none
     DeformFwdSK k;
     HexFeatSK g;
     k.n = g.n = a->num_points;
@@ -604,6 +605,7 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     for (int h = 0; h < 5; ++h) { k.w2[h] = a->p.w2[h]; k.b2[h] = a->p.b2[h]; }
     k.save_hidden = a->save_hidden;
     k.save_act = a->save_act;
+    k.save_mask = reinterpret_cast<uint2*>(a->save_mask);
     k.stamps = nullptr;
 #ifdef EXP_STAMP
     k.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 20));
@@ -1054,6 +1056,9 @@ extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, i
     if (p->matmul == FDGS_MATMUL_SPLIT_BF16) {
         ysplit = (size_t)192 * (bwd_chunk_points(num_points) + 16);      // relu(hidden): 4 column blocks
     }
+#ifdef EXP_STAMP
+    ysplit += (1 << 18);
+#endif
     return (2 * pf + bwd_packed_floats(p->matmul) + per_point * (size_t)num_points +
             (size_t)1280 * bwd_chunk_points(num_points) + ysplit) * sizeof(float);
 }
@@ -1123,7 +1128,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     DeformBwdSK ks;
     k.n = ks.n = n;
     if (split) {
-        if (!a->act) return FDGS_EINVAL;
+        if (!a->act || !a->mask) return FDGS_EINVAL;
         u32x4* pk = reinterpret_cast<u32x4*>(ws_packed);
         SFragTable t;
         t.n = 0;
@@ -1138,7 +1143,8 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         rc = launch_pack_split(t, s);
         if (rc != FDGS_OK) return rc;
         for (int h = 0; h < 5; ++h) ks.w2[h] = a->p.w2[h];
-        ks.act = a->act;
+        ks.mask = reinterpret_cast<const uint2*>(a->mask);
+        ks.n_total = n;
     } else {
         float* pk = ws_packed;
         FragTable t;
@@ -1157,7 +1163,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         if (rc != FDGS_OK) return rc;
     }
     for (int h = 0; h < 5; ++h) k.b1[h] = a->p.b1[h];
-    k.hidden = ks.hidden = a->hidden;
+    k.hidden = a->hidden;
     k.g[0] = a->g_xyz; k.g[1] = a->g_scales; k.g[2] = a->g_rotations; k.g[3] = a->g_opacity; k.g[4] = a->g_shs;
     k.ws_a1 = ws_a1; k.ws_dh1 = ks.ws_dh1 = ws_dh1; k.ws_dhid = ks.ws_dhid = ws_dhid;
     k.ws_df = ks.ws_df = ws_df;
@@ -1234,10 +1240,10 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         if (split) {
             DeformBwdSK sc = ks;
             sc.n = cn;
-            sc.hidden = kc.hidden;
-            sc.act = a->act + (size_t)c0 * 640;
+            sc.p_first = c0;
             for (int h = 0; h < 5; ++h) sc.g[h] = kc.g[h];
             sc.ws_dhid = kc.ws_dhid; sc.ws_df = kc.ws_df;
+            sc.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 20));
             hipLaunchKernelGGL(deform_bwd_points_split_kernel, dim3((cn + 32 * SCB - 1) / (32 * SCB)), dim3(64), 0, s, sc);
         } else {
             hipLaunchKernelGGL(deform_bwd_points_kernel, dim3((cn + 32 * NCB - 1) / (32 * NCB)), dim3(64), 0, s, kc);

@@ -302,6 +302,34 @@ hexplane_features_split_kernel(HexFeatSK a) {
     }
 }
 
+// ReLU masks.  Lane (c, h) owns 64 of a point's 128 features (accumulator registers r of blocks nb);
+// bit 31 - (16 (nb & 1) + r) of word nb >> 1 is SET when the value is NOT positive.  A positive float has
+// an integer image n in [1, 0x7f800000]; for every other float (zeros of both signs, negatives) n <= 0 as a
+// signed integer, and bit 31 of n | (n - 1) is exactly "n <= 0".  v_alignbit shifts that bit in: three vector
+// instructions per value to build, two (bfe + and) to apply.
+__device__ __forceinline__ uint2 relu_mask_build(const floatx16* x) {
+    unsigned w[2] = {0u, 0u};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+        {
+            const unsigned n = __float_as_uint(x[nb][r]);
+            w[nb >> 1] = __builtin_amdgcn_alignbit(w[nb >> 1], n | (n - 1u), 31);
+        }
+    return make_uint2(w[0], w[1]);
+}
+__device__ __forceinline__ void relu_mask_apply(uint2 m, floatx16* x) {
+    const unsigned w[2] = {m.x, m.y};
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int neg = __builtin_amdgcn_sbfe((int)w[nb >> 1], 31 - (16 * (nb & 1) + r), 1);   // -1 if masked
+            x[nb][r] = __uint_as_float(__float_as_uint(x[nb][r]) & ~(unsigned)neg);
+        }
+}
+
 // ---------------------------------------------------------------------------
 // Forward, kernel 2: the MLP.  One wave = 64 points (two column blocks), whole
 // register file, no LDS.
@@ -316,6 +344,7 @@ struct DeformFwdSK {
     float* out[5];
     float* save_hidden;                              // optional [n,128]: hidden, pre-activation
     float* save_act;                                 // optional [n,640]: relu(h1) of the five heads
+    uint2* save_mask;                                // optional [6][n][2]: ReLU masks of the heads' h1 and of hidden
     unsigned long long* stamps;                      // EXP_STAMP builds only
 };
 
@@ -377,6 +406,7 @@ deform_fwd_split_kernel(DeformFwdSK a) {
         for (int cb = 0; cb < SCB; ++cb) {
             const int p = base + 32 * cb + c;
             if (p < a.n) {
+                a.save_mask[((size_t)5 * a.n + p) * 2 + h] = relu_mask_build(hid[cb]);
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -421,6 +451,7 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             for (int cb = 0; cb < SCB; ++cb) {
                 const int p = base + 32 * cb + c;
                 if (p < a.n) {
+                    a.save_mask[((size_t)head * a.n + p) * 2 + h] = relu_mask_build(h1[cb]);
 #pragma unroll
                     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
@@ -512,10 +543,11 @@ struct DeformBwdSK {
     const u32x4* pw2t_shs;                       // split W2^T of the shs head: [128 x 48]
     const u32x4* pw0t;                           // split W0^T, rows permuted so that lane half h receives level h
     const float* w2[5];                          // unpacked W2 (small heads)
-    const float* hidden;                         // [n,128] saved by the forward
-    const float* act;                            // [n,640] saved by the forward
+    const uint2* mask;                           // [6][n_total][2] ReLU masks saved by the forward
+    int n_total; int p_first;                    // the call's point count and this launch's first point
     const float* g[5];                           // output cotangents
     float* ws_dh1; float* ws_dhid; float* ws_df;
+    unsigned long long* stamps;                  // EXP_STAMP builds only
 };
 
 __global__ void __launch_bounds__(64, 1)
@@ -531,6 +563,15 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
             reinterpret_cast<float4*>(w2s[hd])[i] = reinterpret_cast<const float4*>(src)[i];
     }
     __syncthreads();
+#ifdef EXP_STAMP
+    unsigned long long bst[8];
+#define BST(i) bst[i] = __builtin_amdgcn_s_memtime()
+#define BSTH(i) if (head == 1) bst[i] = __builtin_amdgcn_s_memtime()
+#else
+#define BST(i)
+#define BSTH(i)
+#endif
+    BST(0);
 
     int p[SCB], pc[SCB]; bool pvalid[SCB];
     floatx16 dacc[SCB][4];
@@ -544,11 +585,20 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dacc[cb][nb][r] = 0.0f;
     }
+    // ReLU masks of the five heads and of hidden: 8 bytes per lane each, coalesced
+    uint2 msk[SCB][5], hmsk[SCB];
+#pragma unroll
+    for (int cb = 0; cb < SCB; ++cb) {
+#pragma unroll
+        for (int hd = 0; hd < 5; ++hd) msk[cb][hd] = a.mask[((size_t)hd * a.n_total + a.p_first + pc[cb]) * 2 + h];
+        hmsk[cb] = a.mask[((size_t)5 * a.n_total + a.p_first + pc[cb]) * 2 + h];
+    }
     for (int head = 0; head < 5; ++head) {
         const int k = head_dim(head);
         const u32x4* pw1t = sel5(a.pw1t, head);
         const float* __restrict__ g = sel5(a.g, head);
         floatx16 t[SCB][4];      // dh1
+        BSTH(1);
         // dh1 = W2^T g
         if (k <= 4) {
             float gv[SCB][4];
@@ -610,48 +660,40 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
                     for (int cb = 0; cb < SCB; ++cb) t[cb][nb] = mma_split(w, gsp[cb][j], t[cb][nb]);
                 }
         }
-        // ReLU mask from the saved activation, and dh1 out
+        BSTH(2);
+        // ReLU mask, and dh1 out
 #pragma unroll
-        for (int cb = 0; cb < SCB; ++cb)
+        for (int cb = 0; cb < SCB; ++cb) {
+            relu_mask_apply(sel5(msk[cb], head), t[cb]);
 #pragma unroll
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 av = *reinterpret_cast<const float4*>(a.act + (size_t)pc[cb] * 640 + head * DW + 32 * nb + 8 * q + 4 * h);
-                    if (!(av.x > 0.0f)) t[cb][nb][4 * q] = 0.0f;
-                    if (!(av.y > 0.0f)) t[cb][nb][4 * q + 1] = 0.0f;
-                    if (!(av.z > 0.0f)) t[cb][nb][4 * q + 2] = 0.0f;
-                    if (!(av.w > 0.0f)) t[cb][nb][4 * q + 3] = 0.0f;
-#ifndef EXP_NOSTORE
+                for (int q = 0; q < 4; ++q)
                     if (pvalid[cb])
-#else
-                    if (pvalid[cb] && a.n < 0)
-#endif
                         *reinterpret_cast<float4*>(a.ws_dh1 + (size_t)p[cb] * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
                             make_float4(t[cb][nb][4 * q], t[cb][nb][4 * q + 1], t[cb][nb][4 * q + 2], t[cb][nb][4 * q + 3]);
-                }
+        }
+        BSTH(3);
         split_layer128x4<false>(pw1t, lane, t, dacc);
+        BSTH(4);
     }
+    BST(5);
     floatx16 df[SCB][1];
 #pragma unroll
     for (int cb = 0; cb < SCB; ++cb) {
+        relu_mask_apply(hmsk[cb], dacc[cb]);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 hv = *reinterpret_cast<const float4*>(a.hidden + (size_t)pc[cb] * DW + 32 * nb + 8 * q + 4 * h);
-                if (!(hv.x > 0.0f)) dacc[cb][nb][4 * q] = 0.0f;
-                if (!(hv.y > 0.0f)) dacc[cb][nb][4 * q + 1] = 0.0f;
-                if (!(hv.z > 0.0f)) dacc[cb][nb][4 * q + 2] = 0.0f;
-                if (!(hv.w > 0.0f)) dacc[cb][nb][4 * q + 3] = 0.0f;
+            for (int q = 0; q < 4; ++q)
                 if (pvalid[cb])
                     *reinterpret_cast<float4*>(a.ws_dhid + (size_t)p[cb] * DW + 32 * nb + 8 * q + 4 * h) =
                         make_float4(dacc[cb][nb][4 * q], dacc[cb][nb][4 * q + 1], dacc[cb][nb][4 * q + 2],
                                     dacc[cb][nb][4 * q + 3]);
-            }
 #pragma unroll
         for (int r = 0; r < 16; ++r) df[cb][0][r] = 0.0f;
     }
+    BST(6);
     split_layer128_acc<false, 1>(a.pw0t, lane, dacc, df);
 #pragma unroll
     for (int cb = 0; cb < SCB; ++cb)
@@ -661,6 +703,11 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
                 *reinterpret_cast<float4*>(a.ws_df + (size_t)p[cb] * 32 + 16 * h + 4 * q) =
                     make_float4(df[cb][0][4 * q], df[cb][0][4 * q + 1], df[cb][0][4 * q + 2], df[cb][0][4 * q + 3]);
         }
+#ifdef EXP_STAMP
+    BST(7);
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = bst[i];
+#endif
 }
 
 // ===========================================================================

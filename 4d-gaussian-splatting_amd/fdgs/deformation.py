@@ -162,24 +162,25 @@ class _DeformFunction(torch.autograd.Function):
         hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if need_grad else None
         act = (torch.empty(N, 5 * net.W, device=dev, dtype=torch.float32)
                if need_grad and MATMUL == _lib.MATMUL_SPLIT_BF16 else None)
+        mask = torch.empty(N, 12, device=dev, dtype=torch.int64) if act is not None else None
         P = _fill_params(net)
         ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), time_scalar,
                                ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(outs[4]), ptr(hidden),
-                               ptr(act), ptr(ws), ws_bytes)
+                               ptr(act), ptr(mask), ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_fwd", a)
         ctx.net = net
         ctx.time_scalar = time_scalar
         ctx.param_versions = [p._version for p in params]
         ctx.matmul = MATMUL
-        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act)
+        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act, mask)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_xyz, g_sc, g_ro, g_op, g_sh):
         net = ctx.net
-        xyz_c, time_c, hidden, fwd_ws, act = ctx.saved_tensors
+        xyz_c, time_c, hidden, fwd_ws, act, mask = ctx.saved_tensors
         N = xyz_c.shape[0]
         dev = xyz_c.device
         c = lambda t, like: (torch.zeros_like(like) if t is None else t.to(torch.float32).contiguous())
@@ -202,9 +203,10 @@ class _DeformFunction(torch.autograd.Function):
         planes_cl = ptr(fwd_ws) if unchanged else None
         ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
+        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_bwd", a)
+        _lib.LAST_BWD_WS = ws if _lib.KEEP_BWD_WS else None      # debugging hook (cycle stamps)
         pg = tuple(grads[id(p)] for p in params)
         # net, grad_mode, xyz, scales, rotations, opacity, shs, time, *params
         return (None, None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + pg

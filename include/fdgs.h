@@ -224,6 +224,8 @@ typedef struct {
     /*   act [N,640], relu of the five heads' first Linear: required for the backward when
      *   p.matmul == FDGS_MATMUL_SPLIT_BF16 (that backward recomputes nothing), unused otherwise */
     float* save_act;
+    /*   mask, 96 bytes per point (12 N 64-bit words): the ReLU decisions of those activations, same rule as act */
+    void* save_mask;
     void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
 } fdgs_deform_fwd_args;
@@ -238,6 +240,7 @@ typedef struct {
     const float* time; float time_scalar;
     const float* hidden;             /* [N,128] saved by the forward                */
     const float* act;                /* [N,640] saved by the forward (SPLIT_BF16 only, else may be NULL) */
+    const void* mask;                /* 96 N bytes saved by the forward (SPLIT_BF16 only, else may be NULL) */
     const float* planes_channel_last;/* the forward's workspace (channel-last plane copies) if the parameters have
                                         not changed since, else NULL: the copies are rebuilt inside the workspace */
     /* output cotangents; the residual inputs (scales, rotations, opacity, shs)
