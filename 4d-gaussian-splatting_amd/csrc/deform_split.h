@@ -446,22 +446,26 @@ deform_fwd_split_kernel(DeformFwdSK a) {
         split_layer128x4<true>(pw1, lane, hid, h1);
 #endif
         STAMPH(5);
-        if (SAVE) {
+        auto save_act = [&]() {
+            if (SAVE) {
 #pragma unroll
-            for (int cb = 0; cb < SCB; ++cb) {
-                const int p = base + 32 * cb + c;
-                if (p < a.n) {
-                    a.save_mask[((size_t)head * a.n + p) * 2 + h] = relu_mask_build(h1[cb]);
+                for (int cb = 0; cb < SCB; ++cb) {
+                    const int p = base + 32 * cb + c;
+                    if (p < a.n) {
+                        a.save_mask[((size_t)head * a.n + p) * 2 + h] = relu_mask_build(h1[cb]);
 #pragma unroll
-                    for (int nb = 0; nb < 4; ++nb)
+                        for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            *reinterpret_cast<float4*>(a.save_act + (size_t)p * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
-                                make_float4(fmaxf(h1[cb][nb][4 * q], 0.f), fmaxf(h1[cb][nb][4 * q + 1], 0.f),
-                                            fmaxf(h1[cb][nb][4 * q + 2], 0.f), fmaxf(h1[cb][nb][4 * q + 3], 0.f));
+                            for (int q = 0; q < 4; ++q)
+                                *reinterpret_cast<float4*>(a.save_act + (size_t)p * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
+                                    make_float4(fmaxf(h1[cb][nb][4 * q], 0.f), fmaxf(h1[cb][nb][4 * q + 1], 0.f),
+                                                fmaxf(h1[cb][nb][4 * q + 2], 0.f), fmaxf(h1[cb][nb][4 * q + 3], 0.f));
+                    }
                 }
             }
-        }
+        };
+        // issued below, after this head's residual-input loads: a wait on those loads then does not also wait
+        // for the 32 stores (loads and stores share one in-order counter)
         if (k <= 4) {
             float iv[SCB][4], res[SCB][4];
 #pragma unroll
@@ -470,6 +474,7 @@ deform_fwd_split_kernel(DeformFwdSK a) {
 #pragma unroll
                 for (int o = 0; o < 4; ++o) iv[cb][o] = o < k ? in[(size_t)p * k + o] + b2[o] : 0.0f;
             }
+            save_act();
             small_head(w2s[head], k, h, h1, res);
             STAMPH(6);
 #pragma unroll
@@ -502,6 +507,7 @@ deform_fwd_split_kernel(DeformFwdSK a) {
 #pragma unroll
                 for (int cb = 0; cb < SCB; ++cb) o[cb][ob] = b;
             }
+            save_act();
             split_layer128_acc<true, 2>(pw2, lane, h1, o);
 #pragma unroll
             for (int cb = 0; cb < SCB; ++cb) {
