@@ -93,6 +93,16 @@ class DeformBwdArgs(C.Structure):
                 ("d_xyz", c_p), ("dp", DeformParamGrads), ("workspace", c_p), ("workspace_bytes", c_sz)]
 
 
+ADAM_MAX_TENSORS = 48
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("num_tensors", c_i32), ("step", c_i32), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("lr", c_f * ADAM_MAX_TENSORS), ("numel", c_i64 * ADAM_MAX_TENSORS),
+                ("param", c_p * ADAM_MAX_TENSORS), ("grad", c_p * ADAM_MAX_TENSORS),
+                ("exp_avg", c_p * ADAM_MAX_TENSORS), ("exp_avg_sq", c_p * ADAM_MAX_TENSORS)]
+
+
 # every symbol include/fdgs.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "fdgs_strerror": (C.c_char_p, [C.c_int]),
@@ -107,10 +117,11 @@ SYMBOLS = {
     "fdgs_deform_fwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
     "fdgs_deform_fwd": (C.c_int, [C.POINTER(DeformFwdArgs), c_p]),
     "fdgs_deform_bwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
+    "fdgs_adam_step": (C.c_int, [C.POINTER(AdamArgs), c_p]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def _load():

@@ -189,11 +189,13 @@ class _DeformFunction(torch.autograd.Function):
         g_op = c(g_op, torch.empty(N, 1, device=dev)); g_sh = c(g_sh, torch.empty(N, 16, 3, device=dev))
         params = _trainable(net)
         # one zero-filled flat buffer, viewed per parameter (the library accumulates into it)
-        flat = torch.zeros(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
-        grads, off = {}, 0
+        # (every view starts on a 64-byte boundary so that consumers can use 16-byte accesses)
+        offs, off = [], 0
         for p in params:
-            grads[id(p)] = flat[off:off + p.numel()].view(p.shape)
-            off += p.numel()
+            offs.append(off)
+            off += (p.numel() + 15) // 16 * 16
+        flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        grads = {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
         P = _fill_params(net)
         P.matmul = ctx.matmul
         G = _fill_params(net, grads)

@@ -33,7 +33,11 @@ class TrainStep:
             {"params": [gaussians._rotation], "lr": 0.001, "name": "rotation"},
         ]
         on_gpu = gaussians._xyz.is_cuda
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=bool(fused_adam and on_gpu))
+        if fused_adam and on_gpu:       # one launch for all 40 tensors
+            from .adam import FusedAdam
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self.params = [p for grp in groups for p in grp["params"]]
         self.bucket = dp.GradBucket(self.params)
         n = gaussians._xyz.shape[0]

@@ -256,6 +256,27 @@ typedef struct {
 size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points);
 int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream);
 
+/* ---- Adam ------------------------------------------------------------------------------------
+ * One step of torch.optim.Adam (no weight decay, no amsgrad) over up to 48 tensors in one launch:
+ * the optimizer the reference builds at src/runner/fdgs_trainer.py:262-274 (eps 1e-15, one learning
+ * rate per parameter group) and steps at :204.
+ *   m += (1-beta1)(g-m);  v = beta2 v + (1-beta2) g^2;
+ *   p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)                                */
+#define FDGS_ADAM_MAX_TENSORS 48
+typedef struct {
+    int32_t num_tensors;
+    int32_t step;                                    /* 1-based, shared by all tensors */
+    double beta1, beta2, eps;                        /* doubles, as Python holds them: 1-beta is formed before rounding to fp32 */
+    float lr[FDGS_ADAM_MAX_TENSORS];
+    int64_t numel[FDGS_ADAM_MAX_TENSORS];
+    float* param[FDGS_ADAM_MAX_TENSORS];
+    const float* grad[FDGS_ADAM_MAX_TENSORS];
+    float* exp_avg[FDGS_ADAM_MAX_TENSORS];
+    float* exp_avg_sq[FDGS_ADAM_MAX_TENSORS];
+} fdgs_adam_args;
+
+int fdgs_adam_step(const fdgs_adam_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
