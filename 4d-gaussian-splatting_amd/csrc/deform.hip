@@ -497,8 +497,8 @@ static size_t fwd_packed_floats(int matmul) {
     return t;
 }
 static size_t bwd_packed_floats(int matmul) {
-    if (matmul == FDGS_MATMUL_SPLIT_BF16)     // W0^T, five W1^T, W2^T of the shs head
-        return 4 * (size_t)(sfrag_vec4(32, DW) + 5 * sfrag_vec4(DW, DW) + sfrag_vec4(DW, 48));
+    if (matmul == FDGS_MATMUL_SPLIT_BF16)     // W0^T, five W1^T, five W1 (natural K order), W2^T of the shs head
+        return 4 * (size_t)(sfrag_vec4(32, DW) + 10 * sfrag_vec4(DW, DW) + sfrag_vec4(DW, 48));
     size_t t = frag_floats(32, DW);
     for (int h = 0; h < 5; ++h) t += 2 * frag_floats(DW, DW) + frag_floats(DW, h_head_dim[h]);
     return t;
@@ -560,7 +560,7 @@ static size_t fwd_split_bias_floats() { return DW + 5 * DW + 5 * 64; }
 static size_t fwd_split_feat_floats(int n) { return (size_t)((n + 31) / 32) * 2 * 3 * 64 * 4; }
 
 static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
-    if ((a->save_hidden == nullptr) != (a->save_act == nullptr) || (a->save_act == nullptr) != (a->save_mask == nullptr))
+    if ((a->save_hidden == nullptr) != (a->save_mask == nullptr) || (a->save_hidden == nullptr) != (a->save_act == nullptr))
         return FDGS_EINVAL;                                                        // all three or none
     DeformFwdSK k;
     HexFeatSK g;
@@ -604,7 +604,7 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     k.out[4] = a->out_shs;
     for (int h = 0; h < 5; ++h) { k.w2[h] = a->p.w2[h]; k.b2[h] = a->p.b2[h]; }
     k.save_hidden = a->save_hidden;
-    k.save_act = a->save_act;
+    k.save_act = reinterpret_cast<u32x4*>(a->save_act);
     k.save_mask = reinterpret_cast<uint2*>(a->save_mask);
     k.stamps = nullptr;
 #ifdef EXP_STAMP
@@ -613,7 +613,7 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     hipLaunchKernelGGL(hexplane_features_split_kernel, dim3((a->num_points + 127) / 128), dim3(256), 0, s, g);
     FDGS_CHECK_LAUNCH();
     const int blocks = (a->num_points + 32 * SCB - 1) / (32 * SCB);
-    if (a->save_hidden && a->save_act) hipLaunchKernelGGL(deform_fwd_split_kernel<true>, dim3(blocks), dim3(64), 0, s, k);
+    if (a->save_hidden) hipLaunchKernelGGL(deform_fwd_split_kernel<true>, dim3(blocks), dim3(64), 0, s, k);
     else hipLaunchKernelGGL(deform_fwd_split_kernel<false>, dim3(blocks), dim3(64), 0, s, k);
     FDGS_CHECK_LAUNCH();
     return FDGS_OK;
@@ -1124,11 +1124,12 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             }
     }
     const bool split = a->p.matmul == FDGS_MATMUL_SPLIT_BF16;
+    const u32x4* pw1n[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     DeformBwdK k;
     DeformBwdSK ks;
     k.n = ks.n = n;
     if (split) {
-        if (!a->act || !a->mask) return FDGS_EINVAL;
+        if (!a->mask || !a->act) return FDGS_EINVAL;
         u32x4* pk = reinterpret_cast<u32x4*>(ws_packed);
         SFragTable t;
         t.n = 0;
@@ -1140,6 +1141,10 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         }
         t.d[t.n++] = SFragDesc{a->p.w2[4], pk, DW, 48, DW, FRAG_TRANSPOSE};
         ks.pw2t_shs = pk; pk += sfrag_vec4(DW, 48);
+        for (int h = 0; h < 5; ++h) {
+            t.d[t.n++] = SFragDesc{a->p.w1[h], pk, DW, DW, DW, 0};
+            pw1n[h] = pk; pk += sfrag_vec4(DW, DW);
+        }
         rc = launch_pack_split(t, s);
         if (rc != FDGS_OK) return rc;
         for (int h = 0; h < 5; ++h) ks.w2[h] = a->p.w2[h];
@@ -1281,6 +1286,29 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                 w4.d[h] = WGradSDesc{ws_dh1 + h * DW, 640, y_hidden, a->dp.w1[h], DW, 1, DW, a->dp.b1[h]};
             hipLaunchKernelGGL(deform_wgrad_split_kernel<4>, dim3((chunks + per - 1) / per, 5), dim3(256), 0, s, w4);
             FDGS_CHECK_LAUNCH();
+            // dW2_h = g_h^T relu(h1_h) with h1 recomputed in place (nothing stored), db2_h = column sums of g_h
+            WGrad2SK w2k;
+            w2k.n = cn;
+            const int tiles = (cn + 63) / 64;
+            int tpb = (tiles + 203) / 204;
+            if (tpb < 1) tpb = 1;
+            w2k.tiles_per_block = tpb;
+            w2k.hsplit = reinterpret_cast<const u32x4*>(a->act) + (size_t)(c0 / 32) * 8 * 3 * 64;
+            w2k.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 19));
+            ColSumK cs;
+            cs.n = cn;
+            for (int h = 0; h < 5; ++h) {
+                w2k.pw1n[h] = pw1n[h]; w2k.b1[h] = a->p.b1[h]; w2k.g[h] = kc.g[h]; w2k.dw2[h] = a->dp.w2[h];
+                cs.X[h] = kc.g[h]; cs.ncols[h] = kdim[h]; cs.out[h] = a->dp.b2[h];
+            }
+            w2k.tiles_per_block = tpb = (tiles + 1023) / 1024;       // about 1000 waves per launch
+            hipLaunchKernelGGL(deform_wgrad2_split_kernel<1>, dim3((tiles + tpb - 1) / tpb), dim3(64), 0, s, w2k);
+            FDGS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(deform_wgrad2_split_kernel<2>, dim3((tiles + tpb - 1) / tpb), dim3(64), 0, s, w2k);
+            FDGS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(colsum_kernel, dim3(256, 5), dim3(256), 0, s, cs);
+            FDGS_CHECK_LAUNCH();
+            continue;
         }
         WGradK w;
         w.n = cn;
@@ -1295,7 +1323,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         for (int h = 0; h < 5; ++h) {           // dW2_h[o][kk] = sum_p g[p][o] * a1_h[p][kk]
             WGradDesc& d = w.d[nd++];
             d.X = kc.g[h]; d.ldx = kdim[h]; d.M = kdim[h];
-            d.Y = (split ? a->act + (size_t)c0 * 640 : ws_a1) + h * DW; d.ldy = 640; d.NN = DW; d.relu_y = 0;
+            d.Y = ws_a1 + h * DW; d.ldy = 640; d.NN = DW; d.relu_y = 0;
             d.C = a->dp.w2[h]; d.ldc = DW; d.db = a->dp.b2[h];
         }
         for (int i = nd; i < WG_MAX; ++i) {

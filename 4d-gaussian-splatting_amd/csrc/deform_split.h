@@ -89,6 +89,7 @@ __device__ __forceinline__ floatx16 mma_split(const Split3& a, const Split3& b, 
 // lane (pieces h, m, l), lane (c, g) holding element(32 ib + c, kidx(j, g, e)).
 // ---------------------------------------------------------------------------
 #define FRAG_BIAS 8          // not a matrix: a bias vector, copied and zero-padded
+#define FRAG_NATK 16         // natural K order: kidx(j, g, e) = 16 j + 8 g + e (operand loaded from memory rows)
 struct SFragDesc { const float* src; u32x4* dst; int I; int K; int ld; int mode; };
 struct SFragTable { SFragDesc d[FRAG_MAX]; int n; };
 
@@ -117,7 +118,9 @@ pack_split_kernel(SFragTable t) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int kk = (d.mode & FRAG_FEATMAP) ? (16 * g + 8 * j + e) : (16 * j + 8 * (e >> 2) + 4 * g + (e & 3));
+            const int kk = (d.mode & FRAG_FEATMAP) ? (16 * g + 8 * j + e)
+                         : (d.mode & FRAG_NATK) ? (16 * j + 8 * g + e)
+                                                : (16 * j + 8 * (e >> 2) + 4 * g + (e & 3));
             float x = 0.0f;
             if (i < d.I && kk < d.K)
                 x = (d.mode & FRAG_TRANSPOSE) ? d.src[(size_t)kk * d.ld + col] : d.src[(size_t)col * d.ld + kk];
@@ -133,6 +136,27 @@ __device__ __forceinline__ Split3 sfrag_load(const u32x4* packed, int ib, int J,
     const u32x4* q = packed + (size_t)((ib * J + j) * 3) * 64 + lane;
     Split3 s;
     s.h = q[0]; s.m = q[64]; s.l = q[128];
+    return s;
+}
+
+// Same with the fragment address formed as (wave-uniform base in scalar registers) + (lane * 16): no 64-bit
+// per-lane address is ever materialised.  Inside a loop over point tiles the compiler otherwise hoists one
+// address pair per fragment out of the loop (100+ pairs), spills them, and every reload waits for all loads.
+typedef __attribute__((address_space(1))) const char* gptr_t;    // global address space: global_load, not flat_load
+__device__ __forceinline__ gptr_t uniform_ptr(const void* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (gptr_t)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ Split3 sfrag_load_u(const u32x4* packed, int frag, int lane) {
+    typedef __attribute__((address_space(1))) const u32x4* gvec_t;
+    gptr_t b = uniform_ptr(packed) + (size_t)frag * 3072;
+    const unsigned off = (unsigned)lane * 16u;
+    Split3 s;
+    s.h = *(gvec_t)(b + off);
+    s.m = *(gvec_t)(b + off + 1024);
+    s.l = *(gvec_t)(b + off + 2048);
     return s;
 }
 
@@ -343,7 +367,7 @@ struct DeformFwdSK {
     const float* in[5];                              // residual inputs: xyz, scales, rotations, opacity, shs
     float* out[5];
     float* save_hidden;                              // optional [n,128]: hidden, pre-activation
-    float* save_act;                                 // optional [n,640]: relu(h1) of the five heads
+    u32x4* save_act;                                 // relu(hidden) as split operand pieces: [ceil(n/32)][8][3][64]
     uint2* save_mask;                                // optional [6][n][2]: ReLU masks of the heads' h1 and of hidden
     unsigned long long* stamps;                      // EXP_STAMP builds only
 };
@@ -417,13 +441,24 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             }
         }
     }
-#if 1
     Split3 hs[SCB][8];                   // relu(hidden) split once, shared by the five heads
 #pragma unroll
     for (int cb = 0; cb < SCB; ++cb)
 #pragma unroll
         for (int j = 0; j < 8; ++j) hs[cb][j] = split_acc<true>(hid[cb][j >> 1], j & 1);
-#endif
+    if (SAVE) {                          // the same pieces are the A operand of the dW2 recompute in the backward
+#pragma unroll
+        for (int cb = 0; cb < SCB; ++cb) {
+            const int G = blockIdx.x * SCB + cb;
+            if (G * 32 < a.n) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    u32x4* q = a.save_act + (size_t)((G * 8 + j) * 3) * 64 + lane;
+                    q[0] = hs[cb][j].h; q[64] = hs[cb][j].m; q[128] = hs[cb][j].l;
+                }
+            }
+        }
+    }
     STAMP();
     for (int head = 0; head < 5; ++head) {
         const int k = head_dim(head);
@@ -440,11 +475,7 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             for (int cb = 0; cb < SCB; ++cb) h1[cb][nb] = b;
         }
         STAMPH(4);
-#if 1
         split_layer128x4_pre(pw1, lane, hs, h1);
-#else
-        split_layer128x4<true>(pw1, lane, hid, h1);
-#endif
         STAMPH(5);
         auto save_act = [&]() {
             if (SAVE) {
@@ -453,13 +484,6 @@ deform_fwd_split_kernel(DeformFwdSK a) {
                     const int p = base + 32 * cb + c;
                     if (p < a.n) {
                         a.save_mask[((size_t)head * a.n + p) * 2 + h] = relu_mask_build(h1[cb]);
-#pragma unroll
-                        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                *reinterpret_cast<float4*>(a.save_act + (size_t)p * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
-                                    make_float4(fmaxf(h1[cb][nb][4 * q], 0.f), fmaxf(h1[cb][nb][4 * q + 1], 0.f),
-                                                fmaxf(h1[cb][nb][4 * q + 2], 0.f), fmaxf(h1[cb][nb][4 * q + 3], 0.f));
                     }
                 }
             }
@@ -855,4 +879,180 @@ deform_wgrad_split_kernel(WGradSK a) {
         }
     }
     if (d.rowsum) atomicAdd(d.rowsum + 32 * mb + c, bsum);
+}
+
+
+// ===========================================================================
+// Backward, pass 2b (split form): dW2_h[o][f] = sum_p g_h[p][o] * a1_h[p][f] with
+// a1_h = relu(W1_h relu(hidden) + b1_h) RECOMPUTED in the orientation the product
+// needs, so that relu(h1) is never stored:
+//   C1[m = point][n = f] = sum_k relu(hidden)[point][k] W1[f][k]  A = the split relu(hidden) pieces the forward
+//                                                                 saved, B = the forward's W1 fragments
+// leaves lane (f, g) holding, in accumulator registers 8jj..8jj+7, eight points
+// of column f: exactly the B operand (K = points) of
+//   C2[m = o][n = f] += sum_points g[point][o] a1[point][f]      A = g columns, lane o
+// One wave = (range of points, head); 64 points per step.
+// ===========================================================================
+struct WGrad2SK {
+    int n; int tiles_per_block;                  // 64-point tiles per wave
+    const u32x4* hsplit;                         // relu(hidden) pieces saved by the forward: [ceil(n/32)][8][3][64]
+    const u32x4* pw1n[5];                        // split W1 (the forward's fragments)
+    const float* b1[5];
+    const float* g[5];                           // cotangents [n,k]
+    float* dw2[5];                               // [k,128]
+    unsigned long long* stamps;                  // EXP_STAMP builds only
+};
+
+// NOB = 2: the shs head alone (48 rows = two row blocks).  NOB = 1: the four small heads TOGETHER, their
+// 3 + 3 + 4 + 1 rows packed into one 32-row block (row offsets 0, 3, 6, 10): the A operand of a head is zero
+// outside its rows, so the four products accumulate into the same block and the saved relu(hidden) pieces of a
+// tile are fetched from HBM once for the four heads.
+template <int NOB>
+__global__ void __launch_bounds__(64, 1)
+deform_wgrad2_split_kernel(WGrad2SK a) {
+    const int lane = threadIdx.x;
+    const int c = lane & 31, g = lane >> 5;
+    const int total_tiles = (a.n + 63) / 64;
+    const int t_begin = blockIdx.x * a.tiles_per_block;
+    const int t_end = min(t_begin + a.tiles_per_block, total_tiles);
+    if (t_begin >= t_end) return;
+    const int ngroups = (a.n + 31) / 32;
+    const int head_first = NOB == 1 ? 0 : 4, head_last = NOB == 1 ? 3 : 4;
+    floatx16 c2[NOB][4];
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) c2[ob][fb][r] = 0.0f;
+#ifdef EXP_STAMP
+    unsigned long long ws_[5] = {0, 0, 0, 0, 0};
+#define WST(i) if (tile == t_begin + 1 && head == head_first) ws_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define WST(i)
+#endif
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int p0 = tile * 64;
+        int G[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) G[mb] = min(tile * 2 + mb, ngroups - 1);
+        for (int head = head_first; head <= head_last; ++head) {
+            WST(0);
+            const int k = head_dim(head);
+            const int ro = NOB == 1 ? (head == 0 ? 0 : head == 1 ? 3 : head == 2 ? 6 : 10) : 0;   // first row
+            const u32x4* pw = sel5(a.pw1n, head);
+            const float* __restrict__ gsrc = sel5(a.g, head);
+            const float* __restrict__ b1 = sel5(a.b1, head);
+            float gv[NOB][4][8];
+            floatx16 c1[2][4];                   // [point block][feature block]
+#pragma unroll
+            for (int fb = 0; fb < 4; ++fb) {
+                const float bias = b1[32 * fb + c];
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) c1[mb][fb][r] = bias;
+            }
+            WST(1);
+            // product 1, K = 128 input features; both operands arrive as ready pieces (1 KiB coalesced loads)
+            // the relu(hidden) pieces are unique to the tile (HBM latency): requested HS_AHEAD K chunks ahead
+            constexpr int HS_AHEAD = 3;
+            Split3 f[3], hs[HS_AHEAD + 1][2];
+            f[0] = sfrag_load_u(pw, 0 * 8 + 0, lane);
+            f[1] = sfrag_load_u(pw, 1 * 8 + 0, lane);
+#pragma unroll
+            for (int jj = 0; jj < HS_AHEAD; ++jj)
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) hs[jj][mb] = sfrag_load_u(a.hsplit, G[mb] * 8 + jj, lane);
+#pragma unroll
+            for (int t = 0; t < 32; ++t) {
+                const int j = t >> 2, fb = t & 3;
+                if (t + 2 < 32) f[(t + 2) % 3] = sfrag_load_u(pw, ((t + 2) & 3) * 8 + ((t + 2) >> 2), lane);
+                if (fb == 0 && j + HS_AHEAD < 8) {
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+                        hs[(j + HS_AHEAD) % (HS_AHEAD + 1)][mb] = sfrag_load_u(a.hsplit, G[mb] * 8 + j + HS_AHEAD, lane);
+                }
+                if (t == 22) {
+                    // this step's cotangents: row o of the block, eight points per K chunk (mb, jj); requested late
+                    // in product 1 so that they are not live across all of it
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) {
+                        const int o = 32 * ob + c - ro;
+#pragma unroll
+                        for (int ch = 0; ch < 4; ++ch)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const int p = p0 + 32 * (ch >> 1) + drow(8 * (ch & 1) + e, g);
+                                gv[ob][ch][e] = (o >= 0 && o < k && p < a.n) ? gsrc[(size_t)p * k + o] : 0.0f;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) c1[mb][fb] = mma_split(hs[j % (HS_AHEAD + 1)][mb], f[t % 3], c1[mb][fb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            WST(2);
+            // product 2, K = the 64 points of this step: chunk (mb, jj) = points p0 + 32 mb + drow(8 jj + e, g)
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                Split3 gs[NOB];
+#pragma unroll
+                for (int ob = 0; ob < NOB; ++ob) gs[ob] = split8<false>(gv[ob][ch]);
+#pragma unroll
+                for (int fb = 0; fb < 4; ++fb) {
+                    const Split3 as = split_acc_here<true>(c1[ch >> 1][fb], ch & 1);
+#pragma unroll
+                    for (int ob = 0; ob < NOB; ++ob) c2[ob][fb] = mma_split(gs[ob], as, c2[ob][fb]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            WST(3);
+        }
+    }
+#ifdef EXP_STAMP
+    ws_[4] = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && NOB == 1)
+        for (int i = 0; i < 5; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = ws_[i];
+#endif
+#pragma unroll
+    for (int ob = 0; ob < NOB; ++ob)
+#pragma unroll
+        for (int fb = 0; fb < 4; ++fb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * ob + drow(r, g);
+                int head = 4, o = row;
+                if (NOB == 1) {
+                    head = row < 3 ? 0 : row < 6 ? 1 : row < 10 ? 2 : 3;
+                    o = row - (head == 0 ? 0 : head == 1 ? 3 : head == 2 ? 6 : 10);
+                }
+                float* dw2 = sel5(a.dw2, head);
+                if (row < (NOB == 1 ? 11 : 48) && dw2) atomicAdd(dw2 + (size_t)o * DW + 32 * fb + c, c2[ob][fb][r]);
+            }
+}
+
+// column sums of a small row-major matrix: out[j] += sum_p X[p][j], j < ncols <= 64 (the b2 gradients)
+struct ColSumK { const float* X[5]; int ncols[5]; float* out[5]; int n; };
+__global__ void __launch_bounds__(256)
+colsum_kernel(ColSumK a) {
+    const int hd = blockIdx.y;
+    float* out = sel5(a.out, hd);
+    if (!out) return;
+    const float* __restrict__ X = sel5(a.X, hd);
+    const int nc = sel5(a.ncols, hd);
+    __shared__ float acc[64];
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0.0f;
+    __syncthreads();
+    // flat walk with a stride that is a multiple of the column count: a thread stays in one column
+    const long long total = (long long)a.n * nc;
+    const long long stride = ((long long)gridDim.x * 256 / nc) * nc;
+    const long long tg = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (tg < stride) {
+        float s = 0.0f;
+        for (long long i = tg; i < total; i += stride) s += X[i];
+        atomicAdd(&acc[tg % nc], s);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nc) atomicAdd(out + threadIdx.x, acc[threadIdx.x]);
 }

@@ -160,9 +160,10 @@ class _DeformFunction(torch.autograd.Function):
         # the activations are saved (0.92 GB at 300k points)
         need_grad = grad_mode and any(ctx.needs_input_grad)
         hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if need_grad else None
-        act = (torch.empty(N, 5 * net.W, device=dev, dtype=torch.float32)
-               if need_grad and MATMUL == _lib.MATMUL_SPLIT_BF16 else None)
-        mask = torch.empty(N, 12, device=dev, dtype=torch.int64) if act is not None else None
+        split_saves = need_grad and MATMUL == _lib.MATMUL_SPLIT_BF16
+        # relu(hidden) as operand pieces (768 B/point) and the ReLU bit masks (96 B/point); relu(h1) is recomputed
+        act = torch.empty((N + 31) // 32 * 32, 192, device=dev, dtype=torch.float32) if split_saves else None
+        mask = torch.empty(N, 12, device=dev, dtype=torch.int64) if split_saves else None
         P = _fill_params(net)
         ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)

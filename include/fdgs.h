@@ -221,10 +221,11 @@ typedef struct {
     /* saved for backward (may be NULL when no gradient is needed):
      *   hidden [N,128], the pre-activation output of feature_out                   */
     float* save_hidden;
-    /*   act [N,640], relu of the five heads' first Linear: required for the backward when
-     *   p.matmul == FDGS_MATMUL_SPLIT_BF16 (that backward recomputes nothing), unused otherwise */
-    float* save_act;
-    /*   mask, 96 bytes per point (12 N 64-bit words): the ReLU decisions of those activations, same rule as act */
+    /*   act, 768 bytes per point for ceil(N/32)*32 points: relu(hidden) as split matrix-operand pieces (layout
+     *   private to the library); required together with save_hidden when p.matmul == FDGS_MATMUL_SPLIT_BF16 */
+    void* save_act;
+    /*   mask, 96 bytes per point (12 N 64-bit words): the ReLU decisions of hidden and of the five heads;
+     *   required together with save_hidden when p.matmul == FDGS_MATMUL_SPLIT_BF16, unused otherwise */
     void* save_mask;
     void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
@@ -239,7 +240,7 @@ typedef struct {
     const float* xyz;
     const float* time; float time_scalar;
     const float* hidden;             /* [N,128] saved by the forward                */
-    const float* act;                /* [N,640] saved by the forward (SPLIT_BF16 only, else may be NULL) */
+    const void* act;                 /* saved by the forward (SPLIT_BF16 only, else may be NULL) */
     const void* mask;                /* 96 N bytes saved by the forward (SPLIT_BF16 only, else may be NULL) */
     const float* planes_channel_last;/* the forward's workspace (channel-last plane copies) if the parameters have
                                         not changed since, else NULL: the copies are rebuilt inside the workspace */
