@@ -1246,6 +1246,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             DeformBwdSK sc = ks;
             sc.n = cn;
             sc.p_first = c0;
+            sc.dh1_rows = chunk_cap;
             for (int h = 0; h < 5; ++h) sc.g[h] = kc.g[h];
             sc.ws_dhid = kc.ws_dhid; sc.ws_df = kc.ws_df;
             sc.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 20));
@@ -1283,7 +1284,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             w4.chunks_per_block = per;
             for (int i = 0; i < WGS_MAX; ++i) w4.d[i].C = nullptr;
             for (int h = 0; h < 5; ++h)
-                w4.d[h] = WGradSDesc{ws_dh1 + h * DW, 640, y_hidden, a->dp.w1[h], DW, 1, DW, a->dp.b1[h]};
+                w4.d[h] = WGradSDesc{ws_dh1 + (size_t)h * chunk_cap * DW, DW, y_hidden, a->dp.w1[h], DW, 1, DW, a->dp.b1[h]};
             hipLaunchKernelGGL(deform_wgrad_split_kernel<4>, dim3((chunks + per - 1) / per, 5), dim3(256), 0, s, w4);
             FDGS_CHECK_LAUNCH();
             // dW2_h = g_h^T relu(h1_h) with h1 recomputed in place (nothing stored), db2_h = column sums of g_h

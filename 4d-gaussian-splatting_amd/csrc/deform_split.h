@@ -576,7 +576,8 @@ struct DeformBwdSK {
     const uint2* mask;                           // [6][n_total][2] ReLU masks saved by the forward
     int n_total; int p_first;                    // the call's point count and this launch's first point
     const float* g[5];                           // output cotangents
-    float* ws_dh1; float* ws_dhid; float* ws_df;
+    float* ws_dh1; float* ws_dhid; float* ws_df;  // dh1: [5][dh1_rows][128], one contiguous stream per head
+    size_t dh1_rows;
     unsigned long long* stamps;                  // EXP_STAMP builds only
 };
 
@@ -700,7 +701,7 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     if (pvalid[cb])
-                        *reinterpret_cast<float4*>(a.ws_dh1 + (size_t)p[cb] * 640 + head * DW + 32 * nb + 8 * q + 4 * h) =
+                        *reinterpret_cast<float4*>(a.ws_dh1 + ((size_t)head * a.dh1_rows + p[cb]) * DW + 32 * nb + 8 * q + 4 * h) =
                             make_float4(t[cb][nb][4 * q], t[cb][nb][4 * q + 1], t[cb][nb][4 * q + 2], t[cb][nb][4 * q + 3]);
         }
         BSTH(3);
@@ -838,10 +839,14 @@ deform_wgrad_split_kernel(WGradSK a) {
         for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
     float bsum = 0.0f;
     const float* __restrict__ X = d.X + 32 * mb + c;
-    // one chunk ahead: raw X values and the Y pieces of the next chunk are requested before this chunk's MFMAs
-    float xv[8], xn[8];
-    Split3 ys[NB], yn[NB];
-    auto load_chunk = [&](int ch, float* xo, Split3* yo) {
+    // X is unique to the chunk and the wave (HBM): its eight dwords are requested XA chunks ahead (8 registers
+    // per stage).  The Y pieces of a chunk are the same for the four waves of the workgroup: each wave fetches
+    // one column block from L2 and they are exchanged through LDS (double buffered, one barrier per chunk);
+    // fetched per wave they make this kernel L2-bandwidth bound (12 KiB per 24 MFMAs).
+    constexpr int XA = 4;
+    __shared__ u32x4 ybuf[2][4 * 3 * 64];
+    float xr[XA][8];
+    auto load_x = [&](int ch, float* xo) {
         const int pb = ch * 16;
         if (pb + 16 <= a.n) {
 #pragma unroll
@@ -853,21 +858,49 @@ deform_wgrad_split_kernel(WGradSK a) {
                 xo[e] = p < a.n ? X[(size_t)p * d.ldx] : 0.0f;
             }
         }
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) yo[nb] = sfrag_load(d.ysplit, ch, NB, nb, lane);
     };
-    load_chunk(ch_begin, xv, ys);
-    for (int ch = ch_begin; ch < ch_end; ++ch) {
-        if (ch + 1 < ch_end) load_chunk(ch + 1, xn, yn);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bsum += xv[e];
-        const Split3 xs = split8<false>(xv);
+    for (int i = 0; i < XA; ++i)
+        if (ch_begin + i < ch_end) load_x(ch_begin + i, xr[i]);
+    Split3 ystage;                               // this wave's share (column block mb) of the next chunk
+    if (mb < NB) {
+        ystage = sfrag_load(d.ysplit, ch_begin, NB, mb, lane);
+        ybuf[0][(mb * 3 + 0) * 64 + lane] = ystage.h;
+        ybuf[0][(mb * 3 + 1) * 64 + lane] = ystage.m;
+        ybuf[0][(mb * 3 + 2) * 64 + lane] = ystage.l;
+    }
+    __syncthreads();
+    int it = 0;
+    for (int ch0 = ch_begin; ch0 < ch_end; ch0 += XA) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[nb] = mma_split(xs, ys[nb], acc[nb]);
+        for (int i = 0; i < XA; ++i) {           // ring position i is static: the stages stay in registers
+            const int ch = ch0 + i;
+            if (ch < ch_end) {                   // uniform over the workgroup
+                const int cur = it & 1;
+                if (ch + 1 < ch_end && mb < NB) ystage = sfrag_load(d.ysplit, ch + 1, NB, mb, lane);
+                Split3 ys[NB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xv[e] = xn[e];
+                for (int nb = 0; nb < NB; ++nb) {
+                    ys[nb].h = ybuf[cur][(nb * 3 + 0) * 64 + lane];
+                    ys[nb].m = ybuf[cur][(nb * 3 + 1) * 64 + lane];
+                    ys[nb].l = ybuf[cur][(nb * 3 + 2) * 64 + lane];
+                }
+                float xv[8];
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) ys[nb] = yn[nb];
+                for (int e = 0; e < 8; ++e) { xv[e] = xr[i][e]; bsum += xv[e]; }
+                const Split3 xs = split8<false>(xv);
+                if (ch + XA < ch_end) load_x(ch + XA, xr[i]);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = mma_split(xs, ys[nb], acc[nb]);
+                if (ch + 1 < ch_end && mb < NB) {
+                    ybuf[cur ^ 1][(mb * 3 + 0) * 64 + lane] = ystage.h;
+                    ybuf[cur ^ 1][(mb * 3 + 1) * 64 + lane] = ystage.m;
+                    ybuf[cur ^ 1][(mb * 3 + 2) * 64 + lane] = ystage.l;
+                }
+                __syncthreads();
+                ++it;
+            }
+        }
     }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -936,6 +969,9 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
         int G[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) G[mb] = min(tile * 2 + mb, ngroups - 1);
+#ifdef EXP_HS0
+        G[0] = G[1] = 0;
+#endif
         for (int head = head_first; head <= head_last; ++head) {
             WST(0);
             const int k = head_dim(head);
