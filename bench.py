@@ -156,6 +156,8 @@ def main():
     for i in range(args.warmup):
         step(batch(i))
     sync()
+    with torch.no_grad():       # visible Gaussians of the first training view (recorded, not timed)
+        visible = int((render(train_cams[rank % len(train_cams)], g, deforms, bg)["radii"] > 0).sum())
     _lib.PROFILE = {}
     rendered = []
     t0 = time.perf_counter()
@@ -237,7 +239,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: DyNeRF-shaped synthetic scene, single-view training step "
                                    "per GPU (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + Adam)",
                        "gaussians": args.gaussians, "image": [args.width, args.height], "sh_degree": 3,
-                       "global_batch_views": world, "views_per_gpu": 1, "tile_list_entries": R,
+                       "global_batch_views": world, "views_per_gpu": 1, "visible_gaussians": visible,
+                       "tile_list_entries": R,
                        "parallelism": f"dp{world}",
                        "deform_matmul": ("fp32 in / fp32 accumulate / fp32 out; products formed from an exact "
                                          "three-way bf16 split of both operands, six bf16 MFMA terms (error below "
@@ -245,6 +248,13 @@ def main():
             "train_it_s_fp32_mfma": fp32_mfma,
             "render_fps": fps,
             "kernel_ms": per_call,
+            # deformation MLP, forward + backward: 3 x 187,136 flop per point (fp32 semantics) over the two calls,
+            # against the dense fp32 matrix-core peak (157.3 TFLOP/s); the calls include the HexPlane gather/scatter
+            "roofline_deform_mlp": (lambda t: {"bound": "mfma", "achieved": 3 * 187136.0 * args.gaussians / t / 1e12,
+                                               "peak": 157.3, "unit": "TFLOP/s (fp32-equivalent)",
+                                               "frac": 3 * 187136.0 * args.gaussians / t / 1e12 / 157.3,
+                                               "calls": "fdgs_deform_fwd + fdgs_deform_bwd"})(
+                (avg_ms("fdgs_deform_fwd") + avg_ms("fdgs_deform_bwd")) * 1e-3 or 1.0),
             "roofline": {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dur * 1e3},

@@ -116,3 +116,48 @@ def test_sampled_tiles_forward_backward_300k():
     for k in gin:
         a, b = 2.0 * gin[k].grad, g2[k].grad
         assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 1e-5, k
+
+
+@pytest.mark.parametrize("n", [300000, 600000])
+def test_deformation_full_size_split_vs_fp32_mfma(n):
+    """Deformation forward + backward at the benchmark size and at a size that needs two backward
+    chunks (524288 points per chunk): the split-bf16 path against the fp32-MFMA path of the same
+    library.  Outputs agree to rounding; parameter gradients to 2e-3 of their max-norm (a handful
+    of ReLU decisions within rounding of zero flip between any two correct implementations and move
+    single points' contributions); per-point gradients agree except on those few points."""
+    from fdgs import _lib, deformation, scene_synth as ss
+    from fdgs.deformation import DeformationFields
+    dev = torch.device("cuda:0")
+    res = {}
+    old = deformation.MATMUL
+    try:
+        for name, mode in (("f32", _lib.MATMUL_F32), ("split", _lib.MATMUL_SPLIT_BF16)):
+            deformation.MATMUL = mode
+            torch.manual_seed(0)
+            g = ss.GaussianParams(n, device=dev, requires_grad=True)
+            net = ss.perturb_deformation_(DeformationFields(ss.DYNERF_NET_KWARGS)).to(dev)
+            net.deformation_net.set_aabb(list(ss.SCENE_MAX), list(ss.SCENE_MIN))
+            sh = g.get_features.contiguous()
+            outs = net(g._xyz, g._scaling, g._rotation, g._opacity, sh, 0.37)
+            gen = torch.Generator().manual_seed(5)
+            loss = sum((t * torch.randn(t.shape, generator=gen).to(dev)).sum() for t in outs)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[name] = ([t.detach() for t in outs], g._xyz.grad.detach(),
+                         [(k, p.grad.detach()) for k, p in net.named_parameters() if p.requires_grad])
+            del g, net, outs, loss
+    finally:
+        deformation.MATMUL = old
+    for a, b in zip(res["f32"][0], res["split"][0]):
+        assert float((a - b).abs().max()) <= 2e-6
+    gx_a, gx_b = res["f32"][1], res["split"][1]
+    bad = ((gx_a - gx_b).abs().max(dim=1).values > 1e-4 * float(gx_a.abs().max())).sum()
+    assert int(bad) <= max(4, n // 5000), int(bad)
+    for (k, a), (_, b) in zip(res["f32"][2], res["split"][2]):
+        assert torch.isfinite(b).all(), k
+        scale = float(a.abs().max()) + 1e-30
+        if "grid" in k:     # a texel sums few points: a flipped point shows at its 48 texels
+            frac = float(((a - b).abs() > 1e-4 * scale).float().mean())
+            assert frac <= 0.03, (k, frac)
+        else:               # MLP tensors sum over all points
+            assert float((a - b).abs().max()) <= 2e-3 * scale, k
