@@ -511,9 +511,6 @@ extern "C" size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p, i
     if (!p || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS || num_points < 0) return 0;
     size_t floats = total_plane_floats(p) + fwd_packed_floats(p->matmul);
     if (p->matmul == FDGS_MATMUL_SPLIT_BF16) floats += fwd_split_bias_floats() + fwd_split_feat_floats(num_points);
-#ifdef EXP_STAMP
-    floats += (1 << 18);
-#endif
     return floats * sizeof(float);
 }
 
@@ -606,10 +603,6 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     k.save_hidden = a->save_hidden;
     k.save_act = reinterpret_cast<u32x4*>(a->save_act);
     k.save_mask = reinterpret_cast<uint2*>(a->save_mask);
-    k.stamps = nullptr;
-#ifdef EXP_STAMP
-    k.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 20));
-#endif
     hipLaunchKernelGGL(hexplane_features_split_kernel, dim3((a->num_points + 127) / 128), dim3(256), 0, s, g);
     FDGS_CHECK_LAUNCH();
     const int blocks = (a->num_points + 32 * SCB - 1) / (32 * SCB);
@@ -1056,9 +1049,6 @@ extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, i
     if (p->matmul == FDGS_MATMUL_SPLIT_BF16) {
         ysplit = (size_t)192 * (bwd_chunk_points(num_points) + 16);      // relu(hidden): 4 column blocks
     }
-#ifdef EXP_STAMP
-    ysplit += (1 << 18);
-#endif
     return (2 * pf + bwd_packed_floats(p->matmul) + per_point * (size_t)num_points +
             (size_t)1280 * bwd_chunk_points(num_points) + ysplit) * sizeof(float);
 }
@@ -1249,7 +1239,6 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             sc.dh1_rows = chunk_cap;
             for (int h = 0; h < 5; ++h) sc.g[h] = kc.g[h];
             sc.ws_dhid = kc.ws_dhid; sc.ws_df = kc.ws_df;
-            sc.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 20));
             hipLaunchKernelGGL(deform_bwd_points_split_kernel, dim3((cn + 32 * SCB - 1) / (32 * SCB)), dim3(64), 0, s, sc);
         } else {
             hipLaunchKernelGGL(deform_bwd_points_kernel, dim3((cn + 32 * NCB - 1) / (32 * NCB)), dim3(64), 0, s, kc);
@@ -1295,7 +1284,6 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             if (tpb < 1) tpb = 1;
             w2k.tiles_per_block = tpb;
             w2k.hsplit = reinterpret_cast<const u32x4*>(a->act) + (size_t)(c0 / 32) * 8 * 3 * 64;
-            w2k.stamps = reinterpret_cast<unsigned long long*>((char*)a->workspace + a->workspace_bytes - (1 << 19));
             ColSumK cs;
             cs.n = cn;
             for (int h = 0; h < 5; ++h) {

@@ -89,7 +89,6 @@ __device__ __forceinline__ floatx16 mma_split(const Split3& a, const Split3& b, 
 // lane (pieces h, m, l), lane (c, g) holding element(32 ib + c, kidx(j, g, e)).
 // ---------------------------------------------------------------------------
 #define FRAG_BIAS 8          // not a matrix: a bias vector, copied and zero-padded
-#define FRAG_NATK 16         // natural K order: kidx(j, g, e) = 16 j + 8 g + e (operand loaded from memory rows)
 struct SFragDesc { const float* src; u32x4* dst; int I; int K; int ld; int mode; };
 struct SFragTable { SFragDesc d[FRAG_MAX]; int n; };
 
@@ -118,9 +117,7 @@ pack_split_kernel(SFragTable t) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int kk = (d.mode & FRAG_FEATMAP) ? (16 * g + 8 * j + e)
-                         : (d.mode & FRAG_NATK) ? (16 * j + 8 * g + e)
-                                                : (16 * j + 8 * (e >> 2) + 4 * g + (e & 3));
+            const int kk = (d.mode & FRAG_FEATMAP) ? (16 * g + 8 * j + e) : (16 * j + 8 * (e >> 2) + 4 * g + (e & 3));
             float x = 0.0f;
             if (i < d.I && kk < d.K)
                 x = (d.mode & FRAG_TRANSPOSE) ? d.src[(size_t)kk * d.ld + col] : d.src[(size_t)col * d.ld + kk];
@@ -369,7 +366,6 @@ struct DeformFwdSK {
     float* save_hidden;                              // optional [n,128]: hidden, pre-activation
     u32x4* save_act;                                 // relu(hidden) as split operand pieces: [ceil(n/32)][8][3][64]
     uint2* save_mask;                                // optional [6][n][2]: ReLU masks of the heads' h1 and of hidden
-    unsigned long long* stamps;                      // EXP_STAMP builds only
 };
 
 // hidden^T = W0 f^T + b0 for the SCB point groups of this wave
@@ -402,15 +398,6 @@ deform_fwd_split_kernel(DeformFwdSK a) {
     const int c = lane & 31, h = lane >> 5;
     const int base = blockIdx.x * (32 * SCB);
 
-#ifdef EXP_STAMP
-    unsigned long long stamp[8];
-    int ns = 0;
-#define STAMP() stamp[ns++] = __builtin_amdgcn_s_memtime()
-#define STAMPH(i) if (head == 1) stamp[i] = __builtin_amdgcn_s_memtime()
-#else
-#define STAMP()
-#define STAMPH(i)
-#endif
     // output layers of the four small heads (3+3+4+1 rows of 128) staged in LDS, one row group per head
     __shared__ float w2s[4][4 * DW];
 #pragma unroll
@@ -421,10 +408,8 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             reinterpret_cast<float4*>(w2s[hd])[i] = reinterpret_cast<const float4*>(src)[i];
     }
     __syncthreads();
-    STAMP();
     floatx16 hid[SCB][4];
     split_first_linear(a.feat_split, a.pw0, a.pb0, blockIdx.x * SCB, (a.n + 31) / 32, lane, h, hid);
-    STAMP();
     if (SAVE) {
 #pragma unroll
         for (int cb = 0; cb < SCB; ++cb) {
@@ -459,7 +444,6 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             }
         }
     }
-    STAMP();
     for (int head = 0; head < 5; ++head) {
         const int k = head_dim(head);
         const u32x4* pw1 = sel5(a.pw1, head); const float* pb1 = sel5(a.pb1, head);
@@ -467,16 +451,13 @@ deform_fwd_split_kernel(DeformFwdSK a) {
         const float* __restrict__ b2 = sel5(a.b2, head);
         const float* __restrict__ in = sel5(a.in, head); float* __restrict__ out = sel5(a.out, head);
         floatx16 h1[SCB][4];
-        STAMPH(3);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
             const floatx16 b = bias_block(pb1, nb, h);
 #pragma unroll
             for (int cb = 0; cb < SCB; ++cb) h1[cb][nb] = b;
         }
-        STAMPH(4);
         split_layer128x4_pre(pw1, lane, hs, h1);
-        STAMPH(5);
         auto save_act = [&]() {
             if (SAVE) {
 #pragma unroll
@@ -500,7 +481,6 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             }
             save_act();
             small_head(w2s[head], k, h, h1, res);
-            STAMPH(6);
 #pragma unroll
             for (int cb = 0; cb < SCB; ++cb) {
                 const int p = base + 32 * cb + c;
@@ -550,12 +530,6 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             }
         }
     }
-#ifdef EXP_STAMP
-    stamp[7] = __builtin_amdgcn_s_memtime();
-    if (lane == 0)
-        for (int i = 0; i < 8; ++i)
-            a.stamps[(size_t)blockIdx.x * 8 + i] = stamp[i];
-#endif
 }
 
 // ===========================================================================
@@ -578,7 +552,6 @@ struct DeformBwdSK {
     const float* g[5];                           // output cotangents
     float* ws_dh1; float* ws_dhid; float* ws_df;  // dh1: [5][dh1_rows][128], one contiguous stream per head
     size_t dh1_rows;
-    unsigned long long* stamps;                  // EXP_STAMP builds only
 };
 
 __global__ void __launch_bounds__(64, 1)
@@ -594,15 +567,6 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
             reinterpret_cast<float4*>(w2s[hd])[i] = reinterpret_cast<const float4*>(src)[i];
     }
     __syncthreads();
-#ifdef EXP_STAMP
-    unsigned long long bst[8];
-#define BST(i) bst[i] = __builtin_amdgcn_s_memtime()
-#define BSTH(i) if (head == 1) bst[i] = __builtin_amdgcn_s_memtime()
-#else
-#define BST(i)
-#define BSTH(i)
-#endif
-    BST(0);
 
     int p[SCB], pc[SCB]; bool pvalid[SCB];
     floatx16 dacc[SCB][4];
@@ -629,7 +593,6 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
         const u32x4* pw1t = sel5(a.pw1t, head);
         const float* __restrict__ g = sel5(a.g, head);
         floatx16 t[SCB][4];      // dh1
-        BSTH(1);
         // dh1 = W2^T g
         if (k <= 4) {
             float gv[SCB][4];
@@ -691,7 +654,6 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
                     for (int cb = 0; cb < SCB; ++cb) t[cb][nb] = mma_split(w, gsp[cb][j], t[cb][nb]);
                 }
         }
-        BSTH(2);
         // ReLU mask, and dh1 out
 #pragma unroll
         for (int cb = 0; cb < SCB; ++cb) {
@@ -704,11 +666,8 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
                         *reinterpret_cast<float4*>(a.ws_dh1 + ((size_t)head * a.dh1_rows + p[cb]) * DW + 32 * nb + 8 * q + 4 * h) =
                             make_float4(t[cb][nb][4 * q], t[cb][nb][4 * q + 1], t[cb][nb][4 * q + 2], t[cb][nb][4 * q + 3]);
         }
-        BSTH(3);
         split_layer128x4<false>(pw1t, lane, t, dacc);
-        BSTH(4);
     }
-    BST(5);
     floatx16 df[SCB][1];
 #pragma unroll
     for (int cb = 0; cb < SCB; ++cb) {
@@ -724,7 +683,6 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) df[cb][0][r] = 0.0f;
     }
-    BST(6);
     split_layer128_acc<false, 1>(a.pw0t, lane, dacc, df);
 #pragma unroll
     for (int cb = 0; cb < SCB; ++cb)
@@ -734,11 +692,6 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
                 *reinterpret_cast<float4*>(a.ws_df + (size_t)p[cb] * 32 + 16 * h + 4 * q) =
                     make_float4(df[cb][0][4 * q], df[cb][0][4 * q + 1], df[cb][0][4 * q + 2], df[cb][0][4 * q + 3]);
         }
-#ifdef EXP_STAMP
-    BST(7);
-    if (lane == 0)
-        for (int i = 0; i < 8; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = bst[i];
-#endif
 }
 
 // ===========================================================================
@@ -933,7 +886,6 @@ struct WGrad2SK {
     const float* b1[5];
     const float* g[5];                           // cotangents [n,k]
     float* dw2[5];                               // [k,128]
-    unsigned long long* stamps;                  // EXP_STAMP builds only
 };
 
 // NOB = 2: the shs head alone (48 rows = two row blocks).  NOB = 1: the four small heads TOGETHER, their
@@ -958,22 +910,12 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) c2[ob][fb][r] = 0.0f;
-#ifdef EXP_STAMP
-    unsigned long long ws_[5] = {0, 0, 0, 0, 0};
-#define WST(i) if (tile == t_begin + 1 && head == head_first) ws_[i] = __builtin_amdgcn_s_memtime()
-#else
-#define WST(i)
-#endif
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int p0 = tile * 64;
         int G[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) G[mb] = min(tile * 2 + mb, ngroups - 1);
-#ifdef EXP_HS0
-        G[0] = G[1] = 0;
-#endif
         for (int head = head_first; head <= head_last; ++head) {
-            WST(0);
             const int k = head_dim(head);
             const int ro = NOB == 1 ? (head == 0 ? 0 : head == 1 ? 3 : head == 2 ? 6 : 10) : 0;   // first row
             const u32x4* pw = sel5(a.pw1n, head);
@@ -989,7 +931,6 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c1[mb][fb][r] = bias;
             }
-            WST(1);
             // product 1, K = 128 input features; both operands arrive as ready pieces (1 KiB coalesced loads)
             // the relu(hidden) pieces are unique to the tile (HBM latency): requested HS_AHEAD K chunks ahead
             constexpr int HS_AHEAD = 3;
@@ -1028,7 +969,6 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
                 for (int mb = 0; mb < 2; ++mb) c1[mb][fb] = mma_split(hs[j % (HS_AHEAD + 1)][mb], f[t % 3], c1[mb][fb]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            WST(2);
             // product 2, K = the 64 points of this step: chunk (mb, jj) = points p0 + 32 mb + drow(8 jj + e, g)
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
@@ -1043,14 +983,8 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            WST(3);
         }
     }
-#ifdef EXP_STAMP
-    ws_[4] = __builtin_amdgcn_s_memtime();
-    if (lane == 0 && NOB == 1)
-        for (int i = 0; i < 5; ++i) a.stamps[(size_t)blockIdx.x * 8 + i] = ws_[i];
-#endif
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll

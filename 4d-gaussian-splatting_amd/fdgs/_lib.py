@@ -70,7 +70,6 @@ class DeformParams(C.Structure):
 
 
 MATMUL_F32, MATMUL_SPLIT_BF16 = 0, 1
-KEEP_BWD_WS, LAST_BWD_WS = False, None
 
 
 class DeformParamGrads(C.Structure):

@@ -209,7 +209,6 @@ class _DeformFunction(torch.autograd.Function):
         a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_bwd", a)
-        _lib.LAST_BWD_WS = ws if _lib.KEEP_BWD_WS else None      # debugging hook (cycle stamps)
         pg = tuple(grads[id(p)] for p in params)
         # net, grad_mode, xyz, scales, rotations, opacity, shs, time, *params
         return (None, None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + pg
