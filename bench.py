@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1352)
     ap.add_argument("--height", type=int, default=1014)
     ap.add_argument("--render-frames", type=int, default=60, help="frames of the inference-only FPS leg (0 = skip)")
+    ap.add_argument("--scale-mult", type=float, default=1.0, help="multiplier on the Gaussian scales (0.6 for the 2M case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32-mfma-steps", type=int, default=10,
                     help="steps of the extra leg that forms the deformation matrix products with fp32 MFMA (0 = skip)")
@@ -46,7 +47,7 @@ def build_scene(args, dev):
     from fdgs.deformation import DeformationFields
     from fdgs.renderer import render
     from fdgs.train_step import DeformHolder
-    g = ss.GaussianParams(args.gaussians, device=dev)
+    g = ss.GaussianParams(args.gaussians, device=dev, scale_mult=args.scale_mult)
     net = DeformationFields(ss.DYNERF_NET_KWARGS)
     ss.perturb_deformation_(net)
     net = net.to(dev)
@@ -57,7 +58,8 @@ def build_scene(args, dev):
     cams = ss.make_cameras(21, args.width, args.height, device=dev)
     bg = torch.ones(3, device=dev)            # white_background: true (dynerf.yaml:57)
     # ground truth: a render of a second, differently seeded scene (dense L1 gradients)
-    g2 = ss.GaussianParams(args.gaussians, seed=ss.SEED + 100, device=dev, requires_grad=False)
+    g2 = ss.GaussianParams(args.gaussians, seed=ss.SEED + 100, device=dev, requires_grad=False,
+                           scale_mult=args.scale_mult)
     with torch.no_grad():
         for cam in cams:
             cam.original_image = render(cam, g2, deforms, bg, stage="coarse")["render"].clamp(0, 1).clone()
