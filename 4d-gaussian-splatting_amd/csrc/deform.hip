@@ -612,6 +612,41 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     return FDGS_OK;
 }
 
+static bool planes_ok(const fdgs_deform_params* p) {
+    if (!p || p->num_levels != 2 || !p->aabb) return false;
+    for (int l = 0; l < 2; ++l) {
+        for (int ci = 0; ci < 6; ++ci)
+            if (!p->planes[l][ci]) return false;
+        for (int k = 0; k < 4; ++k)
+            if (p->res[l][k] < 2) return false;
+    }
+    return true;
+}
+
+extern "C" size_t fdgs_hexplane_features_workspace_bytes(const fdgs_deform_params* p, int32_t num_points) {
+    if (!p || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS || num_points < 0) return 0;
+    return (total_plane_floats(p) + fwd_split_feat_floats(num_points)) * sizeof(float);
+}
+
+extern "C" int fdgs_hexplane_features(const fdgs_hexplane_features_args* a, void* stream) {
+    if (!a || a->num_points < 0 || !planes_ok(&a->p)) return FDGS_EINVAL;
+    if (a->num_points == 0) return FDGS_OK;
+    if (!a->xyz || !a->features || !a->workspace) return FDGS_EINVAL;
+    if (a->workspace_bytes < fdgs_hexplane_features_workspace_bytes(&a->p, a->num_points)) return FDGS_EWORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    HexFeatSK g;
+    g.n = a->num_points;
+    float* ws = (float*)a->workspace;
+    int rc = make_plane_set(&a->p, ws, &g.ps, true, s);
+    if (rc != FDGS_OK) return rc;
+    g.aabb = a->p.aabb; g.xyz = a->xyz; g.time = a->time; g.time_scalar = a->time_scalar;
+    g.feat_split = reinterpret_cast<u32x4*>(ws + total_plane_floats(&a->p));
+    g.feat_f32 = a->features;
+    hipLaunchKernelGGL(hexplane_features_split_kernel, dim3((a->num_points + 127) / 128), dim3(256), 0, s, g);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}
+
 extern "C" int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream) {
     if (!a || a->num_points < 0 || !params_ok(&a->p)) return FDGS_EINVAL;
     if (a->num_points == 0) return FDGS_OK;

@@ -92,6 +92,11 @@ class DeformBwdArgs(C.Structure):
                 ("d_xyz", c_p), ("dp", DeformParamGrads), ("workspace", c_p), ("workspace_bytes", c_sz)]
 
 
+class HexFeaturesArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("p", DeformParams), ("xyz", c_p), ("time", c_p), ("time_scalar", c_f),
+                ("features", c_p), ("workspace", c_p), ("workspace_bytes", c_sz)]
+
+
 ADAM_MAX_TENSORS = 48
 
 
@@ -116,11 +121,13 @@ SYMBOLS = {
     "fdgs_deform_fwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
     "fdgs_deform_fwd": (C.c_int, [C.POINTER(DeformFwdArgs), c_p]),
     "fdgs_deform_bwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
+    "fdgs_hexplane_features_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
+    "fdgs_hexplane_features": (C.c_int, [C.POINTER(HexFeaturesArgs), c_p]),
     "fdgs_adam_step": (C.c_int, [C.POINTER(AdamArgs), c_p]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def _load():

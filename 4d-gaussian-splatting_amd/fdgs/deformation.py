@@ -68,6 +68,38 @@ class HexPlaneField(nn.Module):
         aabb = torch.tensor([list(map(float, xyz_max)), list(map(float, xyz_min))], dtype=torch.float32, device=dev)
         self.aabb = nn.Parameter(aabb, requires_grad=False)
 
+    @torch.no_grad()
+    def get_density(self, pts, timestamps=None):
+        """Multi-level plane features [N, 32] at (pts, timestamps) (src/model/hexplane.py:182-196).
+        Forward only: gradients flow through DeformationFields.forward, which fuses this step."""
+        pts = pts.reshape(-1, pts.shape[-1]).detach().to(torch.float32).contiguous()
+        n = pts.shape[0]
+        _lib.require_gpu(pts, self.aabb)
+        if isinstance(timestamps, (float, int)):
+            time_scalar, time_c = float(timestamps), None
+        else:
+            time_scalar, time_c = 0.0, timestamps.detach().to(torch.float32).reshape(-1).contiguous()
+            if time_c.numel() != n:
+                raise ValueError("timestamps must have one entry per point")
+        P = _lib.DeformParams()
+        P.num_levels = len(self.grids)
+        for l, reso in enumerate(self.resolutions):
+            for k in range(4):
+                P.res[l][k] = int(reso[k])
+        P.aabb = ptr(self.aabb.detach())
+        for l, gp in enumerate(self.grids):
+            for ci in range(6):
+                P.planes[l][ci] = ptr(gp[ci])
+        out = torch.empty(n, self.feat_dim, device=pts.device, dtype=torch.float32)
+        ws_bytes = lib.fdgs_hexplane_features_workspace_bytes(C.byref(P), n)
+        ws = torch.empty(max(ws_bytes, 16), device=pts.device, dtype=torch.uint8)
+        a = _lib.HexFeaturesArgs(n, P, ptr(pts), ptr(time_c), time_scalar, ptr(out), ptr(ws), ws_bytes)
+        _lib.call("fdgs_hexplane_features", a)
+        return out
+
+    def forward(self, pts, timestamps=None):
+        return self.get_density(pts, timestamps)
+
 
 def _head(width, out_dim):
     return nn.Sequential(nn.ReLU(), nn.Linear(width, width), nn.ReLU(), nn.Linear(width, out_dim))

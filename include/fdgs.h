@@ -257,6 +257,22 @@ typedef struct {
 size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points);
 int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream);
 
+/* HexPlane features alone (forward only): HexPlaneField.forward / get_density, src/model/hexplane.py:182-204.
+ * features [N, 16 * num_levels]; time as in fdgs_deform_fwd_args.  Only p.res, p.aabb and p.planes are read. */
+typedef struct {
+    int32_t num_points;
+    fdgs_deform_params p;
+    const float* xyz;                /* [N,3]                                       */
+    const float* time;               /* [N,1] or NULL to use time_scalar            */
+    float time_scalar;
+    float* features;                 /* [N,32]                                      */
+    void* workspace;                 /* fdgs_hexplane_features_workspace_bytes(&p, N) bytes */
+    size_t workspace_bytes;
+} fdgs_hexplane_features_args;
+
+size_t fdgs_hexplane_features_workspace_bytes(const fdgs_deform_params* p, int32_t num_points);
+int fdgs_hexplane_features(const fdgs_hexplane_features_args* a, void* stream);
+
 /* ---- Adam ------------------------------------------------------------------------------------
  * One step of torch.optim.Adam (no weight decay, no amsgrad) over up to 48 tensors in one launch:
  * the optimizer the reference builds at src/runner/fdgs_trainer.py:262-274 (eps 1e-15, one learning

@@ -99,3 +99,23 @@ def test_split_products_are_fp32_accurate():
         deformation.MATMUL = old
     assert errs["f32"] <= 2e-6 and errs["split"] <= 2e-6, errs
     assert errs["split"] <= 2.0 * errs["f32"] + 2e-7, errs
+
+
+@pytest.mark.parametrize("case,n", [("tiny", 333), ("dynerf", None)])
+def test_hexplane_features_alone(case, n):
+    """HexPlaneField.forward / get_density (src/model/hexplane.py:182-204): the [N,32] plane features,
+    per-point times and one scalar time, N not a multiple of the kernel's point group."""
+    dev = torch.device("cuda:0")
+    net, sd = _module(case, dev)
+    xyz, _, _, _, _, tm = dc.make_inputs(case)
+    if n is not None:
+        xyz, tm = xyz[:n], tm[:n]
+    grid = net.deformation_net.grid
+    ref = deform_ref.hexplane_features(sd, xyz, tm)
+    got = grid(xyz.to(dev), tm.to(dev))
+    assert got.shape == ref.shape == (xyz.shape[0], 32)
+    assert float((got.cpu() - ref).abs().max()) <= 1e-6
+    ref1 = deform_ref.hexplane_features(sd, xyz, torch.full_like(tm, 0.25))
+    got1 = grid.get_density(xyz.to(dev), 0.25)
+    assert float((got1.cpu() - ref1).abs().max()) <= 1e-6
+    assert grid(xyz[:0].to(dev), tm[:0].to(dev)).shape == (0, 32)
