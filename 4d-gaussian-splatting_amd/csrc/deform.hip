@@ -102,6 +102,7 @@ struct PlaneSet {                        // two levels x six planes, channel-las
 
 struct Bilinear {                        // one lookup: 4 texel offsets (in texels) and weights
     int o00, o01, o10, o11;
+    int x0, y0;                          // texel coordinates of corner 00
     float w00, w01, w10, w11;
     float fx, fy;                        // fractional parts
     bool in_x, in_y;                     // coordinate strictly inside (gradient flows)
@@ -131,6 +132,7 @@ __device__ __forceinline__ Bilinear make_bilinear(float ca, float cb, int Wd, in
     b.w10 = (1.0f - b.fx) * b.fy;
     b.w11 = b.fx * b.fy;
     b.o00 = y0 * Wd + x0; b.o01 = y0 * Wd + x1; b.o10 = y1 * Wd + x0; b.o11 = y1 * Wd + x1;
+    b.x0 = x0; b.y0 = y0;
     return b;
 }
 
@@ -993,6 +995,8 @@ hexplane_bwd_kernel(HexBwdK a, int lds_floats) {
     }
 }
 
+#include "hexplane_bricks.h"
+
 // ---------------------------------------------------------------------------
 // Pass 2: C[m][n] += sum_p X[p][m] * Y[p][n]   (+ db[m] += sum_p X[p][m])
 // ---------------------------------------------------------------------------
@@ -1076,16 +1080,24 @@ static int bwd_chunk_points(int n) {
     return c < 1 ? 1 : c;
 }
 
+// pre-split operands of the weight-gradient products: relu(hidden), 4 column blocks
+static size_t bwd_ysplit_floats(int matmul, int n) {
+    return matmul == FDGS_MATMUL_SPLIT_BF16 ? (size_t)192 * (bwd_chunk_points(n) + 16) : 0;
+}
+// brick binning of the HexPlane backward, in 4-byte words: perm [n], brick_of [n] (16 bit, rounded up),
+// counts / cursor [BRICK_MAX] each, work count (16 words), work items [3 x max_work]
+static int brick_max_work(int n) { return BRICK_MAX + n / BRICK_CH + 1; }
+static size_t bwd_brick_words(int n) {
+    return (size_t)n + ((size_t)n + 1) / 2 + 2 * BRICK_MAX + 16 + (size_t)3 * brick_max_work(n);
+}
+
 extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points) {
     if (!p || num_points < 0 || p->num_levels < 1 || p->num_levels > FDGS_DEFORM_MAX_LEVELS) return 0;
     const size_t pf = total_plane_floats(p);
     const size_t per_point = DW + 32 + 32;
-    size_t ysplit = 0;                     // pre-split operands of the weight-gradient products
-    if (p->matmul == FDGS_MATMUL_SPLIT_BF16) {
-        ysplit = (size_t)192 * (bwd_chunk_points(num_points) + 16);      // relu(hidden): 4 column blocks
-    }
     return (2 * pf + bwd_packed_floats(p->matmul) + per_point * (size_t)num_points +
-            (size_t)1280 * bwd_chunk_points(num_points) + ysplit) * sizeof(float);
+            (size_t)1280 * bwd_chunk_points(num_points) + bwd_ysplit_floats(p->matmul, num_points) +
+            bwd_brick_words(num_points)) * sizeof(float);
 }
 
 // The HexPlane scatter (atomics-bound) and the weight-gradient products (matrix-core / memory-bound) only
@@ -1132,6 +1144,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
 
     float* ws_df = ws_feat + (size_t)32 * n;
     float* ws_ysplit = ws_df + (size_t)32 * n;      // split mode only (sized by fdgs_deform_bwd_workspace_bytes)
+    int* ws_brick = reinterpret_cast<int*>(ws_ysplit + bwd_ysplit_floats(a->p.matmul, n));
 
     HexBwdK hk;
     hk.n = n;
@@ -1203,16 +1216,69 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
         hk.ws_df = ws_df; hk.ws_feat = ws_feat; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
         hk.lds_time = (a->time == nullptr) ? 1 : 0;
-        int hex_lds_floats = 0;
-        for (int l = 0; l < 2; ++l)
-            for (int tp = 0; tp < 3; ++tp) hex_lds_floats += 2 * a->p.res[l][tp] * DF;
-        if ((size_t)hex_lds_floats * sizeof(float) > 150 * 1024) { hk.lds_time = 0; }
-        const size_t hex_lds_bytes = hk.lds_time ? (size_t)hex_lds_floats * sizeof(float) : 0;
-        if (hex_lds_bytes > 64 * 1024 &&
-            hipFuncSetAttribute((const void*)hexplane_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)hex_lds_bytes) != hipSuccess)
-            return FDGS_ELAUNCH;
-        {
+        // brick path: float64 windows of all twelve planes in LDS; the coarsest brick grid whose windows fit
+        HexBrickK bk;
+        int brick_lds_doubles = 0;
+        bool bricks = false;
+        const char* mode = getenv("FDGS_HEX_BWD");
+        if (!(mode && mode[0] == 'f')) {            // FDGS_HEX_BWD=flat keeps the one-atomic-per-corner kernel
+            static const int cand[4][3] = {{8, 8, 8}, {8, 8, 16}, {8, 16, 16}, {16, 16, 16}};
+            int first = 0, last = 3;
+            if (mode && mode[0] >= '0' && mode[0] <= '3') first = last = mode[0] - '0';
+            for (int ci = first; ci <= last && !bricks; ++ci) {
+                int fl = 0;
+                for (int l = 0; l < 2; ++l) {
+                    int tw[3];
+                    for (int ax = 0; ax < 3; ++ax) tw[ax] = bk.tw[l][ax] = (a->p.res[l][ax] - 1) / cand[ci][ax] + 3;
+                    fl += (tw[0] * tw[1] + tw[0] * tw[2] + tw[1] * tw[2]) * DF;
+                    if (hk.lds_time) fl += (tw[0] + tw[1] + tw[2]) * DF;
+                }
+                if ((size_t)fl * sizeof(double) <= 128 * 1024) {
+                    bricks = true;
+                    brick_lds_doubles = fl;
+                    for (int ax = 0; ax < 3; ++ax) bk.nb[ax] = cand[ci][ax];
+                }
+            }
+        }
+        if (bricks) {
+            BrickBinK bb;
+            bb.n = n; bb.xyz = a->xyz; bb.aabb = a->p.aabb;
+            bb.perm = ws_brick;
+            bb.brick_of = reinterpret_cast<unsigned short*>(ws_brick + n);
+            bb.counts = ws_brick + n + (n + 1) / 2;
+            bb.cursor = bb.counts + BRICK_MAX;
+            bb.work_count = bb.cursor + BRICK_MAX;
+            bb.work = bb.work_count + 16;
+            for (int ax = 0; ax < 3; ++ax) bb.nb[ax] = bk.nb[ax];
+            const int nbr = bk.nb[0] * bk.nb[1] * bk.nb[2];
+            if (hipMemsetAsync(bb.counts, 0, (size_t)nbr * sizeof(int), hs) != hipSuccess) return FDGS_ELAUNCH;
+            const int sort_blocks = (n + BRICK_SORT_PTS - 1) / BRICK_SORT_PTS;
+            hipLaunchKernelGGL(brick_hist_kernel, dim3(sort_blocks), dim3(256), 0, hs, bb);
+            FDGS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(brick_plan_kernel, dim3(1), dim3(1024), 0, hs, bb);
+            FDGS_CHECK_LAUNCH();
+            hipLaunchKernelGGL(brick_scatter_kernel, dim3(sort_blocks), dim3(256), 0, hs, bb);
+            FDGS_CHECK_LAUNCH();
+            bk.h = hk; bk.perm = bb.perm; bk.work = bb.work; bk.work_count = bb.work_count;
+            const size_t bytes = (size_t)brick_lds_doubles * sizeof(double);
+            if (bytes > 64 * 1024 &&
+                hipFuncSetAttribute((const void*)hexplane_bwd_brick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes) != hipSuccess)
+                return FDGS_ELAUNCH;
+            int max_work = nbr + n / BRICK_CH + 1;          // <= brick_max_work(n)
+            if (max_work > n) max_work = n;
+            hipLaunchKernelGGL(hexplane_bwd_brick_kernel, dim3(max_work), dim3(BRICK_THREADS), bytes, hs, bk, brick_lds_doubles);
+            FDGS_CHECK_LAUNCH();
+        } else {
+            int hex_lds_floats = 0;
+            for (int l = 0; l < 2; ++l)
+                for (int tp = 0; tp < 3; ++tp) hex_lds_floats += 2 * a->p.res[l][tp] * DF;
+            if ((size_t)hex_lds_floats * sizeof(float) > 150 * 1024) { hk.lds_time = 0; }
+            const size_t hex_lds_bytes = hk.lds_time ? (size_t)hex_lds_floats * sizeof(float) : 0;
+            if (hex_lds_bytes > 64 * 1024 &&
+                hipFuncSetAttribute((const void*)hexplane_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)hex_lds_bytes) != hipSuccess)
+                return FDGS_ELAUNCH;
             const long long waves_needed = ((long long)2 * n + 3) / 4;
             long long hb = (waves_needed + 3) / 4;
             if (hb > 512) hb = 512;

@@ -119,3 +119,36 @@ def test_hexplane_features_alone(case, n):
     got1 = grid.get_density(xyz.to(dev), 0.25)
     assert float((got1.cpu() - ref1).abs().max()) <= 1e-6
     assert grid(xyz[:0].to(dev), tm[:0].to(dev)).shape == (0, 32)
+
+
+@pytest.mark.parametrize("hex_bwd", ["bricks", "flat", "3"])
+def test_scalar_time_backward_matches_oracle(hex_bwd, monkeypatch):
+    """One time stamp for the whole call (how render() calls the field): the HexPlane backward then keeps the
+    time-plane rows in LDS.  Checked against autograd through the oracle, for the brick kernel (default and the
+    finest brick grid) and for the one-atomic-per-corner kernel, with some points outside the box (clipped to its faces)."""
+    if hex_bwd != "bricks":
+        monkeypatch.setenv("FDGS_HEX_BWD", hex_bwd)
+    dev = torch.device("cuda:0")
+    net, sd = _module("tiny", dev)
+    xyz, sc, ro, op, sh, _ = dc.make_inputs("tiny")
+    n = 700
+    xyz, sc, ro, op, sh = (t[:n].clone() for t in (xyz, sc, ro, op, sh))
+    aabb = sd["deformation_net.grid.aabb"]
+    xyz[16:32] = aabb[0] + (aabb[0] - aabb[1]) * 0.25  # outside: clipped to the border
+    xyz[32:48] = aabb[1] - (aabb[0] - aabb[1]) * 0.25
+    tval = 0.37
+    gouts = [g[:n] for g in dc.make_grad_outputs("tiny")]
+    # oracle: autograd through the CPU restatement
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point() and "aabb" not in k) for k, v in sd.items()}
+    xr = xyz.clone().requires_grad_(True)
+    ref = deform_ref.deform_forward(sdr, xr, sc, ro, op, sh, torch.full((n, 1), tval))
+    tkeys = dc.trainable_keys(sd)
+    ref_g = torch.autograd.grad(ref, [xr] + [sdr[k] for k in tkeys], gouts, allow_unused=True)
+    xg = xyz.to(dev).requires_grad_(True)
+    outs = net(xg, sc.to(dev), ro.to(dev), op.to(dev), sh.to(dev), tval)
+    params = dict(net.named_parameters())
+    got = torch.autograd.grad(outs, [xg] + [params[k] for k in tkeys], [g.to(dev) for g in gouts])
+    torch.cuda.synchronize()
+    for name, g, r in zip(["xyz"] + tkeys, got, ref_g):
+        r = torch.zeros_like(g.cpu()) if r is None else r
+        assert _rel(g.cpu(), r) <= GRAD_TOL, (hex_bwd, name)
