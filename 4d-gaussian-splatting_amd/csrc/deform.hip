@@ -1396,7 +1396,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             FDGS_CHECK_LAUNCH();
             hipLaunchKernelGGL(deform_wgrad2_split_kernel<2>, dim3((tiles + tpb - 1) / tpb), dim3(64), 0, s, w2k);
             FDGS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(colsum_kernel, dim3(256, 5), dim3(256), 0, s, cs);
+            hipLaunchKernelGGL(colsum_kernel, dim3(1024, 5), dim3(256), 0, s, cs);
             FDGS_CHECK_LAUNCH();
             continue;
         }

@@ -1019,9 +1019,13 @@ colsum_kernel(ColSumK a) {
     const long long stride = ((long long)gridDim.x * 256 / nc) * nc;
     const long long tg = (long long)blockIdx.x * 256 + threadIdx.x;
     if (tg < stride) {
-        float s = 0.0f;
-        for (long long i = tg; i < total; i += stride) s += X[i];
-        atomicAdd(&acc[tg % nc], s);
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;     // four loads in flight per thread
+        long long i = tg;
+        for (; i + 3 * stride < total; i += 4 * stride) {
+            s0 += X[i]; s1 += X[i + stride]; s2 += X[i + 2 * stride]; s3 += X[i + 3 * stride];
+        }
+        for (; i < total; i += stride) s0 += X[i];
+        atomicAdd(&acc[tg % nc], (s0 + s1) + (s2 + s3));
     }
     __syncthreads();
     if ((int)threadIdx.x < nc) atomicAdd(out + threadIdx.x, acc[threadIdx.x]);
