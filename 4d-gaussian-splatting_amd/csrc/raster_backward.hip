@@ -107,7 +107,7 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
         const float pvy = V[1] * x + V[5] * y + V[9] * z + V[13];
         const float pvz = V[2] * x + V[6] * y + V[10] * z + V[14];
         const float mod = a.scale_modifier;
-        float sx = 0.f, sy = 0.f, sz = 0.f, qr = 1.f, qx = 0.f, qy = 0.f, qz = 0.f;
+        float sx = 0.f, sy = 0.f, sz = 0.f, qr = 1.f, qx = 0.f, qy = 0.f, qz = 0.f, qinv = 1.f;
         float R00 = 0.f, R01 = 0.f, R02 = 0.f, R10 = 0.f, R11 = 0.f, R12 = 0.f, R20 = 0.f, R21 = 0.f, R22 = 0.f;
         float M00 = 0.f, M01 = 0.f, M02 = 0.f, M10 = 0.f, M11 = 0.f, M12 = 0.f, M20 = 0.f, M21 = 0.f, M22 = 0.f;
         float c00, c01, c02, c11, c12, c22;
@@ -115,8 +115,14 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
             const float* __restrict__ cv = a.cov3D_precomp + (size_t)i * 6;
             c00 = cv[0]; c01 = cv[1]; c02 = cv[2]; c11 = cv[3]; c12 = cv[4]; c22 = cv[5];
         } else {
-            sx = mod * a.scales[3 * i + 0]; sy = mod * a.scales[3 * i + 1]; sz = mod * a.scales[3 * i + 2];
+            sx = a.scales[3 * i + 0]; sy = a.scales[3 * i + 1]; sz = a.scales[3 * i + 2];
+            if (a.activations & FDGS_ACT_SCALE_EXP) { sx = expf(sx); sy = expf(sy); sz = expf(sz); }
+            sx *= mod; sy *= mod; sz *= mod;
             qr = a.rotations[4 * i + 0]; qx = a.rotations[4 * i + 1]; qy = a.rotations[4 * i + 2]; qz = a.rotations[4 * i + 3];
+            if (a.activations & FDGS_ACT_ROTATION_NORMALIZE) {
+                qinv = 1.0f / fmaxf(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
+                qr *= qinv; qx *= qinv; qy *= qinv; qz *= qinv;
+            }
             R00 = 1.0f - 2.0f * (qy * qy + qz * qz); R01 = 2.0f * (qx * qy - qr * qz); R02 = 2.0f * (qx * qz + qr * qy);
             R10 = 2.0f * (qx * qy + qr * qz); R11 = 1.0f - 2.0f * (qx * qx + qz * qz); R12 = 2.0f * (qy * qz - qr * qx);
             R20 = 2.0f * (qx * qz - qr * qy); R21 = 2.0f * (qy * qz + qr * qx); R22 = 1.0f - 2.0f * (qx * qx + qy * qy);
@@ -205,6 +211,19 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
             drot[1] = 2.0f * (qy * r01 + qz * r02 + qy * r10 - 2.0f * qx * r11 - qr * r12 + qz * r20 + qr * r21 - 2.0f * qx * r22);
             drot[2] = 2.0f * (-2.0f * qy * r00 + qx * r01 + qr * r02 + qx * r10 + qz * r12 - qr * r20 + qz * r21 - 2.0f * qy * r22);
             drot[3] = 2.0f * (-2.0f * qz * r00 - qr * r01 + qx * r02 + qr * r10 - 2.0f * qz * r11 + qy * r12 + qx * r20 + qy * r21);
+            // chain through the activations: d exp = exp, d (q/|q|) = (I - q^ q^T) / |q|
+            if (a.activations & FDGS_ACT_SCALE_EXP) {       // mod * exp(raw) = sx
+                dscale[0] *= sx / mod; dscale[1] *= sy / mod; dscale[2] *= sz / mod;
+            }
+            if (a.activations & FDGS_ACT_ROTATION_NORMALIZE) {
+                const float along = qinv > 0.5e12f ? 0.0f : (qr * drot[0] + qx * drot[1] + qy * drot[2] + qz * drot[3]);
+                drot[0] = (drot[0] - qr * along) * qinv; drot[1] = (drot[1] - qx * along) * qinv;
+                drot[2] = (drot[2] - qy * along) * qinv; drot[3] = (drot[3] - qz * along) * qinv;
+            }
+        }
+        if (a.activations & FDGS_ACT_OPACITY_SIGMOID) {     // geom keeps the activated opacity
+            const float o = geom4[1].y;
+            dop *= o * (1.0f - o);
         }
 
         // ---- pixel position through the perspective projection ----

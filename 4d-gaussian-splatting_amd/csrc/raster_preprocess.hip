@@ -51,9 +51,15 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
             c00 = cv[0]; c01 = cv[1]; c02 = cv[2]; c11 = cv[3]; c12 = cv[4]; c22 = cv[5];
         } else {
             const float mod = a.scale_modifier;
-            const float sx = mod * a.scales[3 * i + 0], sy = mod * a.scales[3 * i + 1], sz = mod * a.scales[3 * i + 2];
-            const float qr = a.rotations[4 * i + 0], qx = a.rotations[4 * i + 1];
-            const float qy = a.rotations[4 * i + 2], qz = a.rotations[4 * i + 3];
+            float s0 = a.scales[3 * i + 0], s1 = a.scales[3 * i + 1], s2 = a.scales[3 * i + 2];
+            if (a.activations & FDGS_ACT_SCALE_EXP) { s0 = expf(s0); s1 = expf(s1); s2 = expf(s2); }
+            const float sx = mod * s0, sy = mod * s1, sz = mod * s2;
+            float qr = a.rotations[4 * i + 0], qx = a.rotations[4 * i + 1];
+            float qy = a.rotations[4 * i + 2], qz = a.rotations[4 * i + 3];
+            if (a.activations & FDGS_ACT_ROTATION_NORMALIZE) {
+                const float inv = 1.0f / fmaxf(sqrtf(qr * qr + qx * qx + qy * qy + qz * qz), 1e-12f);
+                qr *= inv; qx *= inv; qy *= inv; qz *= inv;
+            }
             const float R00 = 1.0f - 2.0f * (qy * qy + qz * qz);
             const float R01 = 2.0f * (qx * qy - qr * qz);
             const float R02 = 2.0f * (qx * qz + qr * qy);
@@ -166,7 +172,8 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
             cr = res[0]; cg = res[1]; cb = res[2];
         }
     }
-    const float op = visible ? a.opacities[i] : 0.0f;
+    float op = visible ? a.opacities[i] : 0.0f;
+    if (visible && (a.activations & FDGS_ACT_OPACITY_SIGMOID)) op = 1.0f / (1.0f + expf(-op));
     grec[0] = make_float4(px, py, conA, conB);
     grec[1] = make_float4(conC, op, cr, cg);
     grec[2] = make_float4(cb, pvz, __int_as_float(radius), __int_as_float(clampmask));

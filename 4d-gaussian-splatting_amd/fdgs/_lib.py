@@ -30,7 +30,7 @@ class PreprocessFwdArgs(C.Structure):
                 ("means3D", c_p), ("scales", c_p), ("rotations", c_p), ("opacities", c_p), ("shs", c_p),
                 ("colors_precomp", c_p), ("cov3D_precomp", c_p),
                 ("geom", c_p), ("radii", c_p), ("tiles_touched", c_p), ("point_offsets", c_p),
-                ("scan_workspace", c_p)]
+                ("scan_workspace", c_p), ("activations", c_i32)]
 
 
 class BinSortArgs(C.Structure):
@@ -60,7 +60,11 @@ class PreprocessBwdArgs(C.Structure):
                 ("colors_precomp", c_p), ("cov3D_precomp", c_p),
                 ("geom", c_p), ("dL_dgeom", c_p),
                 ("dL_dmeans3D", c_p), ("dL_dmeans2D", c_p), ("dL_dscales", c_p), ("dL_drotations", c_p),
-                ("dL_dopacities", c_p), ("dL_dshs", c_p), ("dL_dcolors", c_p), ("dL_dcov3D", c_p)]
+                ("dL_dopacities", c_p), ("dL_dshs", c_p), ("dL_dcolors", c_p), ("dL_dcov3D", c_p),
+                ("activations", c_i32)]
+
+
+ACT_SCALE_EXP, ACT_ROTATION_NORMALIZE, ACT_OPACITY_SIGMOID = 1, 2, 4
 
 
 class DeformParams(C.Structure):
@@ -127,7 +131,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def _load():

@@ -47,9 +47,10 @@ class RasterState:
 
 
 def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=False, colors_precomp=None,
-                      cov3D_precomp=None):
+                      cov3D_precomp=None, activations=0):
     """Runs stages 1-6 through the C ABI and returns a RasterState.  Either shs or colors_precomp [N,3],
-    either (scales, rotations) or cov3D_precomp [N,6]."""
+    either (scales, rotations) or cov3D_precomp [N,6].  `activations` (ACT_* flags of fdgs._lib) marks
+    scales / rotations / opacities as raw parameters whose activation the preprocess kernel applies."""
     _lib.require_gpu(means3D, shs, opacities, scales, rotations, colors_precomp, cov3D_precomp, S.bg, S.viewmatrix,
                      S.projmatrix, S.campos)
     dev = means3D.device
@@ -68,7 +69,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     a = _lib.PreprocessFwdArgs(N, int(S.sh_degree), W, H, float(S.tanfovx), float(S.tanfovy), float(S.scale_modifier),
                                ptr(vm), ptr(pm), ptr(cp), ptr(means3D), ptr(scales), ptr(rotations), ptr(opacities),
                                ptr(shs), ptr(colors_precomp), ptr(cov3D_precomp), ptr(st.geom), ptr(st.radii), ptr(st.tiles_touched), ptr(st.point_offsets),
-                               ptr(scan_ws))
+                               ptr(scan_ws), int(activations))
     _lib.call("fdgs_raster_preprocess_fwd", a)
 
     # the data-dependent list length R: one small device->host read (stream sync)
@@ -99,7 +100,8 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     return st
 
 
-def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, colors_precomp=None, cov3D_precomp=None):
+def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, colors_precomp=None, cov3D_precomp=None,
+                       activations=0):
     dev = means3D.device
     N = means3D.shape[0]
     H, W = int(S.image_height), int(S.image_width)
@@ -127,7 +129,7 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, color
                                float(S.scale_modifier), ptr(vm), ptr(pm), ptr(cp), ptr(means3D), ptr(scales),
                                ptr(rotations), ptr(shs), ptr(colors_precomp), ptr(cov3D_precomp), ptr(st.geom),
                                ptr(dgeom), ptr(d_means3D), ptr(d_means2D), ptr(d_scales), ptr(d_rot), ptr(d_op),
-                               ptr(d_shs), ptr(d_colors), ptr(d_cov))
+                               ptr(d_shs), ptr(d_colors), ptr(d_cov), int(activations))
     _lib.call("fdgs_raster_preprocess_bwd", b)
     return dict(means3D=d_means3D, means2D=d_means2D, shs=d_shs, colors=d_colors, opacities=d_op, scales=d_scales,
                 rotations=d_rot, cov3D=d_cov, geom=dgeom)
@@ -135,12 +137,14 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, color
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, S):
+    def forward(ctx, means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, S,
+                activations=0):
         opt = lambda t: None if t is None else _f32c(t)
         m3, sh, cp = _f32c(means3D), opt(shs), opt(colors_precomp)
         op, sc, ro, cv = _f32c(opacities).reshape(-1), opt(scales), opt(rotations), opt(cov3D_precomp)
-        st = rasterize_forward(m3, sh, op, sc, ro, S, colors_precomp=cp, cov3D_precomp=cv)
+        st = rasterize_forward(m3, sh, op, sc, ro, S, colors_precomp=cp, cov3D_precomp=cv, activations=activations)
         ctx.S = S
+        ctx.activations = activations
         ctx.st = st
         ctx.inputs = (m3, sh, cp, sc, ro, cv)
         ctx.op_shape = opacities.shape
@@ -150,11 +154,12 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_color, _grad_radii, _grad_depth):
         m3, sh, cp, sc, ro, cv = ctx.inputs
-        g = rasterize_backward(ctx.st, grad_color, m3, sh, sc, ro, ctx.S, colors_precomp=cp, cov3D_precomp=cv)
+        g = rasterize_backward(ctx.st, grad_color, m3, sh, sc, ro, ctx.S, colors_precomp=cp, cov3D_precomp=cv,
+                               activations=ctx.activations)
         ctx.st = None
         ctx.inputs = None
         return (g["means3D"], g["means2D"], g["shs"], g["colors"], g["opacities"].reshape(ctx.op_shape), g["scales"],
-                g["rotations"], g["cov3D"], None)
+                g["rotations"], g["cov3D"], None, None)
 
 
 class GaussianRasterizer(nn.Module):
@@ -163,7 +168,10 @@ class GaussianRasterizer(nn.Module):
         self.raster_settings = raster_settings
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, activations=0):
+        """The reference's call (src/gaussian_renderer/__init__.py:104-113).  `activations` is an extension:
+        ACT_* flags of fdgs._lib say which of scales / rotations / opacities are still raw parameters; their
+        exp / normalize / sigmoid then runs inside the preprocess kernels (forward and backward)."""
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide exactly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -172,4 +180,4 @@ class GaussianRasterizer(nn.Module):
         if shs is not None and tuple(shs.shape[1:]) != (16, 3):
             raise ValueError("shs must be [N,16,3] (SH degree 3 storage)")
         return _RasterizeGaussians.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                         cov3D_precomp, self.raster_settings)
+                                         cov3D_precomp, self.raster_settings, int(activations))

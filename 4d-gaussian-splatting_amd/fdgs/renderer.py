@@ -16,6 +16,7 @@ import math
 
 import torch
 
+from . import _lib
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -74,10 +75,23 @@ def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifi
     else:
         raise NotImplementedError
 
+    # the activations of :83-86.  The reference's own three callables (src/model/gaussian_model.py:22-26) are
+    # evaluated inside the rasterizer's preprocess kernels; anything else is called here as the reference does
+    activations = 0
     if scales_final is not None:
-        scales_final = pc.scaling_activation(scales_final)
-        rotations_final = pc.rotation_activation(rotations_final)
-    opacity = pc.opacity_activation(opacity_final)
+        if pc.scaling_activation is torch.exp:
+            activations |= _lib.ACT_SCALE_EXP
+        else:
+            scales_final = pc.scaling_activation(scales_final)
+        if pc.rotation_activation is torch.nn.functional.normalize:
+            activations |= _lib.ACT_ROTATION_NORMALIZE
+        else:
+            rotations_final = pc.rotation_activation(rotations_final)
+    if pc.opacity_activation is torch.sigmoid:
+        activations |= _lib.ACT_OPACITY_SIGMOID
+        opacity = opacity_final
+    else:
+        opacity = pc.opacity_activation(opacity_final)
 
     colors_precomp = None
     if override_color is None:
@@ -95,7 +109,7 @@ def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifi
 
     rendered_image, radii, depth = rasterizer(
         means3D=means3D_final, means2D=means2D, shs=shs_final, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp)
+        scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp, activations=activations)
     return {"render": rendered_image,
             "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0,

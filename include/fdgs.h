@@ -59,6 +59,14 @@ int fdgs_abi_version(void);
  *   [8] b      [9] view depth [10] radius (int32 bits) [11] SH clamp mask (int32 bits, bit c = channel c clamped)
  */
 
+/* Activations that the reference's render() applies between the deformation field and the rasterizer
+ * (src/gaussian_renderer/__init__.py:83-86, callables of src/model/gaussian_model.py:22-26), evaluated
+ * inside the preprocess kernels instead: scale = exp(raw), rotation = raw / max(|raw|, 1e-12),
+ * opacity = sigmoid(raw).  0 keeps the rasterizer's own interface (activated inputs). */
+#define FDGS_ACT_SCALE_EXP 1
+#define FDGS_ACT_ROTATION_NORMALIZE 2
+#define FDGS_ACT_OPACITY_SIGMOID 4
+
 /* ---- rasterizer forward, stage 1+2: per-Gaussian preprocess + inclusive scan --------------- */
 typedef struct {
     int32_t num_points;
@@ -83,6 +91,7 @@ typedef struct {
     uint32_t* tiles_touched;         /* [N]                                         */
     uint32_t* point_offsets;         /* [N]   inclusive scan of tiles_touched; R = point_offsets[N-1] */
     uint32_t* scan_workspace;        /* fdgs_raster_scan_workspace_bytes(N) bytes   */
+    int32_t activations;             /* FDGS_ACT_* flags: scales / rotations / opacities are raw parameters */
 } fdgs_preprocess_fwd_args;
 
 size_t fdgs_raster_scan_workspace_bytes(int32_t num_points);
@@ -168,6 +177,7 @@ typedef struct {
     float* dL_dshs;                  /* [N,16,3]   (SH path)                        */
     float* dL_dcolors;               /* [N,3]      (colors_precomp path)            */
     float* dL_dcov3D;                /* [N,6]      (cov3D_precomp path)             */
+    int32_t activations;             /* as in the forward call; the gradients are then w.r.t. the raw tensors */
 } fdgs_preprocess_bwd_args;
 
 int fdgs_raster_preprocess_bwd(const fdgs_preprocess_bwd_args* a, void* stream);

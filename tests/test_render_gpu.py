@@ -67,3 +67,42 @@ def test_render_contract_and_flags():
         col = torch.full((pc.get_xyz.shape[0], 3), 0.25, device="cuda")
         o4 = render(cam, pc, deforms, bg, stage=stage, override_color=col)
         assert float(o4["render"].min()) >= 0.25 - 1e-5 and float(o4["render"].max()) <= 1.0 + 1e-5
+
+
+def test_activations_inside_the_rasterizer_match_torch():
+    """render() leaves exp / normalize / sigmoid (src/gaussian_renderer/__init__.py:83-86) to the preprocess
+    kernels when the model uses the reference's own callables; wrapping them hides their identity and sends
+    them through PyTorch as the reference does.  Both must give the same image and parameter gradients,
+    and with the deformation field's parameters too in the fine stage."""
+    from fdgs.renderer import render
+    cam, pc, deforms, bg = _scene()
+    with torch.no_grad():
+        pc._rotation[:7] *= 3.0             # far from unit length
+        pc._rotation[7:9] = 0.0             # degenerate: normalize() divides by its eps
+    gen = torch.Generator().manual_seed(5)
+    gout = torch.randn(3, cam.image_height, cam.image_width, generator=gen).cuda()
+    net_params = list(deforms.deformation_fields.parameters())
+    for stage in ("coarse", "fine"):
+        res = {}
+        for mode in ("kernel", "torch"):
+            acts = (pc.scaling_activation, pc.rotation_activation, pc.opacity_activation)
+            if mode == "torch":
+                pc.scaling_activation = lambda t: torch.exp(t)
+                pc.rotation_activation = lambda t: torch.nn.functional.normalize(t)
+                pc.opacity_activation = lambda t: torch.sigmoid(t)
+            try:
+                out = render(cam, pc, deforms, bg, stage=stage)
+                (out["render"] * gout).sum().backward()
+            finally:
+                pc.scaling_activation, pc.rotation_activation, pc.opacity_activation = acts
+            ng = [p.grad.clone() for p in net_params if p.grad is not None]
+            for p in net_params:
+                p.grad = None
+            res[mode] = (out["render"].detach(), out["radii"].clone(), out["viewspace_points"].grad.clone(), _grads(pc), ng)
+        k, t = res["kernel"], res["torch"]
+        assert int((k[1] != t[1]).sum()) <= 2                       # ceil(3 sigma) ties under 1-ulp scale changes
+        assert float((k[0] - t[0]).abs().max()) <= 1e-5
+        assert float((k[2] - t[2]).abs().max() / (t[2].abs().max() + 1e-30)) <= 1e-4
+        assert len(k[4]) == len(t[4])
+        for a, b in zip(k[3] + k[4], t[3] + t[4]):
+            assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 1e-4
