@@ -101,6 +101,19 @@ class HexFeaturesArgs(C.Structure):
                 ("features", c_p), ("workspace", c_p), ("workspace_bytes", c_sz)]
 
 
+class L1FwdArgs(C.Structure):
+    _fields_ = [("n", c_i64), ("a", c_p), ("b", c_p), ("scale", c_f), ("loss", c_p), ("partial", c_p)]
+
+
+class L1BwdArgs(C.Structure):
+    _fields_ = [("n", c_i64), ("a", c_p), ("b", c_p), ("scale", c_f), ("grad_loss", c_p), ("grad_a", c_p)]
+
+
+class DensifyStatsArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("radii", c_p), ("viewspace_grad", c_p), ("max_radii2D", c_p),
+                ("xyz_gradient_accum", c_p), ("denom", c_p)]
+
+
 ADAM_MAX_TENSORS = 48
 
 
@@ -127,11 +140,15 @@ SYMBOLS = {
     "fdgs_deform_bwd_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
     "fdgs_hexplane_features_workspace_bytes": (c_sz, [C.POINTER(DeformParams), c_i32]),
     "fdgs_hexplane_features": (C.c_int, [C.POINTER(HexFeaturesArgs), c_p]),
+    "fdgs_l1_loss_partials": (c_sz, [c_i64]),
+    "fdgs_l1_loss_fwd": (C.c_int, [C.POINTER(L1FwdArgs), c_p]),
+    "fdgs_l1_loss_bwd": (C.c_int, [C.POINTER(L1BwdArgs), c_p]),
+    "fdgs_densify_stats": (C.c_int, [C.POINTER(DensifyStatsArgs), c_p]),
     "fdgs_adam_step": (C.c_int, [C.POINTER(AdamArgs), c_p]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def _load():

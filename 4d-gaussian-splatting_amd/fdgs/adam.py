@@ -48,8 +48,9 @@ class FusedAdam:
                           "exp_avg_sq": torch.zeros_like(p, memory_format=torch.contiguous_format)}
                     self.state[p] = st
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                _lib.require_gpu(p, grad, st["exp_avg"], st["exp_avg_sq"])
-                if not p.is_contiguous() or p.dtype != torch.float32 or grad.dtype != torch.float32:
+                if not (p.is_cuda and grad.is_cuda):
+                    raise RuntimeError("libfdgs kernels run on the GPU only")
+                if not p.is_contiguous() or p.dtype is not torch.float32 or grad.dtype is not torch.float32:
                     raise ValueError("FusedAdam needs contiguous float32 parameters and gradients")
                 entries.append((p, grad, st, float(g["lr"])))
         if not entries:
@@ -63,8 +64,9 @@ class FusedAdam:
             part = entries[i:i + _lib.ADAM_MAX_TENSORS]
             a = _lib.AdamArgs()
             a.num_tensors, a.step, a.beta1, a.beta2, a.eps = len(part), self._step, b1, b2, eps
+            lrs, numels, pp, gp, mp, vp = a.lr, a.numel, a.param, a.grad, a.exp_avg, a.exp_avg_sq
             for t, (p, grad, st, lr) in enumerate(part):
-                a.lr[t], a.numel[t] = lr, p.numel()
-                a.param[t], a.grad[t] = ptr(p), ptr(grad)
-                a.exp_avg[t], a.exp_avg_sq[t] = ptr(st["exp_avg"]), ptr(st["exp_avg_sq"])
+                lrs[t] = lr; numels[t] = p.numel()
+                pp[t] = p.data_ptr(); gp[t] = grad.data_ptr()
+                mp[t] = st["exp_avg"].data_ptr(); vp[t] = st["exp_avg_sq"].data_ptr()
             _lib.call("fdgs_adam_step", a)

@@ -137,39 +137,59 @@ class DeformationNet(nn.Module):
 MATMUL = {"f32": _lib.MATMUL_F32, "split": _lib.MATMUL_SPLIT_BF16}[os.environ.get("FDGS_DEFORM_MATMUL", "split")]
 
 
-def _fill_params(net, grads=None):
-    """fdgs_deform_params (or the gradient twin) from the module's tensors."""
-    grid = net.grid
-    src = (lambda t: t) if grads is None else (lambda t: grads[id(t)])
-    P = _lib.DeformParams() if grads is None else _lib.DeformParamGrads()
-    if grads is None:
-        P.num_levels = len(grid.grids)
-        for l, reso in enumerate(grid.resolutions):
-            for k in range(4):
-                P.res[l][k] = int(reso[k])
-        P.aabb = ptr(grid.aabb.detach())
-        P.matmul = MATMUL
-    for l, gp in enumerate(grid.grids):
-        for ci in range(6):
-            P.planes[l][ci] = ptr(src(gp[ci]))
-    P.w0 = ptr(src(net.feature_out[0].weight))
-    P.b0 = ptr(src(net.feature_out[0].bias))
-    for h, name in enumerate(HEADS):
-        seq = getattr(net, name + "_deform")
-        P.w1[h] = ptr(src(seq[1].weight)); P.b1[h] = ptr(src(seq[1].bias))
-        P.w2[h] = ptr(src(seq[3].weight)); P.b2[h] = ptr(src(seq[3].bias))
-    return P
-
-
 def _trainable(net):
-    ts = []
-    for gp in net.grid.grids:
-        ts += list(gp)
-    ts += [net.feature_out[0].weight, net.feature_out[0].bias]
-    for name in HEADS:
-        seq = getattr(net, name + "_deform")
-        ts += [seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias]
+    """The 34 trainable tensors in the order of the C structs: 12 planes, w0, b0, then (w1, b1, w2, b2) per
+    head.  The list is built once per module (Parameter objects are stable; their storage may move)."""
+    ts = net.__dict__.get("_fdgs_trainable")
+    if ts is None:
+        ts = []
+        for gp in net.grid.grids:
+            ts += list(gp)
+        ts += [net.feature_out[0].weight, net.feature_out[0].bias]
+        for name in HEADS:
+            seq = getattr(net, name + "_deform")
+            ts += [seq[1].weight, seq[1].bias, seq[3].weight, seq[3].bias]
+        net.__dict__["_fdgs_trainable"] = ts
+        # flat gradient buffer: every tensor whose size is a multiple of 16 floats first (each then starts on a
+        # 64-byte boundary, so consumers can use 16-byte accesses), the five small last-layer biases at the end
+        order = sorted(range(len(ts)), key=lambda i: (ts[i].numel() % 16 != 0, i))
+        net.__dict__["_fdgs_grad_order"] = order
+        net.__dict__["_fdgs_grad_sizes"] = [ts[i].numel() for i in order]
+        net.__dict__["_fdgs_grad_shapes"] = [tuple(ts[i].shape) for i in order]
     return ts
+
+
+def _set_pointers(P, tensors, n_levels):
+    """Writes 34 device pointers (order of _trainable) into a DeformParams / DeformParamGrads struct."""
+    k = 0
+    for l in range(n_levels):
+        row = P.planes[l]
+        for ci in range(6):
+            row[ci] = ptr(tensors[k]); k += 1
+    P.w0 = ptr(tensors[k]); P.b0 = ptr(tensors[k + 1]); k += 2
+    for h in range(5):
+        P.w1[h] = ptr(tensors[k]); P.b1[h] = ptr(tensors[k + 1])
+        P.w2[h] = ptr(tensors[k + 2]); P.b2[h] = ptr(tensors[k + 3])
+        k += 4
+
+
+def _fill_params(net, grads=None):
+    """fdgs_deform_params from the module's tensors, or the gradient twin from `grads` (same order)."""
+    grid = net.grid
+    n_levels = len(grid.resolutions)
+    if grads is not None:
+        G = _lib.DeformParamGrads()
+        _set_pointers(G, grads, n_levels)
+        return G
+    P = _lib.DeformParams()
+    P.num_levels = n_levels
+    for l, reso in enumerate(grid.resolutions):
+        for k in range(4):
+            P.res[l][k] = int(reso[k])
+    P.aabb = ptr(grid.aabb.detach())
+    P.matmul = MATMUL
+    _set_pointers(P, _trainable(net), n_levels)
+    return P
 
 
 class _DeformFunction(torch.autograd.Function):
@@ -178,7 +198,9 @@ class _DeformFunction(torch.autograd.Function):
         _lib.require_gpu(xyz, scales, rotations, opacity, shs, *params)
         N = xyz.shape[0]
         dev = xyz.device
-        c = lambda t: t.detach().to(torch.float32).contiguous()
+        def c(t):
+            t = t.detach()
+            return t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
         xyz_c, sc_c, ro_c, op_c, sh_c = c(xyz), c(scales), c(rotations), c(opacity), c(shs)
         time_scalar = 0.0
         if isinstance(time, (float, int)):
@@ -216,19 +238,19 @@ class _DeformFunction(torch.autograd.Function):
         xyz_c, time_c, hidden, fwd_ws, act, mask = ctx.saved_tensors
         N = xyz_c.shape[0]
         dev = xyz_c.device
-        c = lambda t, like: (torch.zeros_like(like) if t is None else t.to(torch.float32).contiguous())
-        g_xyz = c(g_xyz, xyz_c)
-        g_sc = c(g_sc, torch.empty(N, 3, device=dev)); g_ro = c(g_ro, torch.empty(N, 4, device=dev))
-        g_op = c(g_op, torch.empty(N, 1, device=dev)); g_sh = c(g_sh, torch.empty(N, 16, 3, device=dev))
+        def c(t, shape):
+            if t is None:
+                return torch.zeros(shape, device=dev, dtype=torch.float32)
+            return t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+        g_xyz = c(g_xyz, (N, 3)); g_sc = c(g_sc, (N, 3)); g_ro = c(g_ro, (N, 4))
+        g_op = c(g_op, (N, 1)); g_sh = c(g_sh, (N, 16, 3))
         params = _trainable(net)
         # one zero-filled flat buffer, viewed per parameter (the library accumulates into it)
-        # (every view starts on a 64-byte boundary so that consumers can use 16-byte accesses)
-        offs, off = [], 0
-        for p in params:
-            offs.append(off)
-            off += (p.numel() + 15) // 16 * 16
-        flat = torch.zeros(off, device=dev, dtype=torch.float32)
-        grads = {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(params, offs)}
+        order, sizes, shapes = net._fdgs_grad_order, net._fdgs_grad_sizes, net._fdgs_grad_shapes
+        flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+        grads = [None] * len(params)
+        for i, piece, shape in zip(order, flat.split_with_sizes(sizes), shapes):
+            grads[i] = piece.view(shape)
         P = _fill_params(net)
         P.matmul = ctx.matmul
         G = _fill_params(net, grads)
@@ -241,9 +263,8 @@ class _DeformFunction(torch.autograd.Function):
         a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_bwd", a)
-        pg = tuple(grads[id(p)] for p in params)
         # net, grad_mode, xyz, scales, rotations, opacity, shs, time, *params
-        return (None, None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + pg
+        return (None, None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + tuple(grads)
 
 
 class DeformationFields(nn.Module):

@@ -37,13 +37,15 @@ LAST_NUM_RENDERED = 0     # tile-list length R of the most recent forward (bench
 
 
 def _f32c(t):
-    return t.detach().to(torch.float32).contiguous()
+    if t.requires_grad:
+        t = t.detach()
+    return t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
 
 
 class RasterState:
     """Device buffers produced by the forward stages (kept for backward / inspection)."""
     __slots__ = ("geom", "radii", "tiles_touched", "point_offsets", "num_rendered", "keys_sorted", "vals_sorted",
-                 "ranges", "final_T", "n_contrib", "color", "depth")
+                 "ranges", "final_T", "n_contrib", "color", "depth", "cam")
 
 
 def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=False, colors_precomp=None,
@@ -64,7 +66,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     st.point_offsets = torch.empty(N, device=dev, dtype=torch.int32)
     scan_ws = torch.empty(max(1, lib.fdgs_raster_scan_workspace_bytes(N) // 4), device=dev, dtype=torch.int32)
     vm, pm, cp, bg = _f32c(S.viewmatrix), _f32c(S.projmatrix), _f32c(S.campos), _f32c(S.bg)
-    sp = stream_ptr()
+    st.cam = (vm, pm, cp, bg)
 
     a = _lib.PreprocessFwdArgs(N, int(S.sh_degree), W, H, float(S.tanfovx), float(S.tanfovy), float(S.scale_modifier),
                                ptr(vm), ptr(pm), ptr(cp), ptr(means3D), ptr(scales), ptr(rotations), ptr(opacities),
@@ -105,10 +107,9 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, color
     dev = means3D.device
     N = means3D.shape[0]
     H, W = int(S.image_height), int(S.image_width)
-    vm, pm, cp, bg = _f32c(S.viewmatrix), _f32c(S.projmatrix), _f32c(S.campos), _f32c(S.bg)
-    sp = stream_ptr()
+    vm, pm, cp, bg = st.cam
     dgeom = torch.zeros(N, _lib.GEOM_FLOATS, device=dev, dtype=torch.float32)
-    gc = grad_color.to(torch.float32).contiguous()
+    gc = _f32c(grad_color)
     a = _lib.BlendBwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted), ptr(st.geom), ptr(bg), ptr(st.final_T),
                           ptr(st.n_contrib), ptr(gc), ptr(dgeom))
     _lib.call("fdgs_raster_blend_bwd", a)

@@ -6,7 +6,7 @@ torch.distributed initialised the views are sharded over ranks and gradients
 and statistics are all-reduced (fdgs.dp)."""
 import torch
 
-from . import dp
+from . import dp, losses
 from .renderer import render
 
 
@@ -45,6 +45,17 @@ class TrainStep:
         self.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
         self.denom = torch.zeros(n, 1, device=dev)
         self.max_radii2D = torch.zeros(n, device=dev)
+        self.fused_tail = on_gpu            # L1 loss and densification statistics as single libfdgs passes
+
+    @torch.no_grad()
+    def _stats_torch(self, radii, vis, vgrad):
+        """fdgs_trainer.py:181-182 without boolean indexing (which would synchronise the host on the number
+        of visible points)."""
+        self.max_radii2D = torch.where(vis, torch.max(self.max_radii2D, radii.to(self.max_radii2D.dtype)),
+                                       self.max_radii2D)
+        visf = vis.unsqueeze(-1).to(self.denom.dtype)
+        self.xyz_gradient_accum += torch.norm(vgrad[:, :2], dim=-1, keepdim=True) * visf
+        self.denom += visf
 
     def __call__(self, global_views):
         """global_views: the whole batch (identical on every rank); returns the local loss value tensor."""
@@ -54,7 +65,10 @@ class TrainStep:
         loss = None
         for cam in views:
             pkg = render(cam, self.g, self.deforms, self.bg, stage=self.stage, cam_type="dynerf")
-            l1 = torch.abs(pkg["render"] - cam.original_image).mean() * scale
+            if self.fused_tail:
+                l1 = losses.l1_loss(pkg["render"], cam.original_image, scale)
+            else:
+                l1 = torch.abs(pkg["render"] - cam.original_image).mean() * scale
             loss = l1 if loss is None else loss + l1
             radii_list.append(pkg["radii"])
             vis_list.append(pkg["visibility_filter"])
@@ -63,7 +77,9 @@ class TrainStep:
             loss.backward()
         n = self.g._xyz.shape[0]
         dev = self.g._xyz.device
-        if views:
+        if len(views) == 1:
+            radii, vis, vgrad = radii_list[0], vis_list[0], vsp_list[0].grad
+        elif views:
             radii = torch.stack(radii_list, 0).max(dim=0).values
             vis = torch.stack(vis_list, 0).any(dim=0)
             vgrad = torch.zeros_like(vsp_list[0])
@@ -76,13 +92,10 @@ class TrainStep:
         if dp.is_dist():
             self.bucket.allreduce_()
             radii, vis, vgrad = dp.reduce_densification_stats(radii, vis, vgrad)
-        with torch.no_grad():   # fdgs_trainer.py:181-182, gaussian_model.py:182-184, written without
-            # boolean indexing (which would synchronise the host on the number of visible points)
-            self.max_radii2D = torch.where(vis, torch.max(self.max_radii2D, radii.to(self.max_radii2D.dtype)),
-                                           self.max_radii2D)
-            visf = vis.unsqueeze(-1).to(self.denom.dtype)
-            self.xyz_gradient_accum += torch.norm(vgrad[:, :2], dim=-1, keepdim=True) * visf
-            self.denom += visf
+        if self.fused_tail:     # fdgs_trainer.py:181-182, gaussian_model.py:182-184 in one launch
+            losses.add_densification_stats(radii, vgrad, self.xyz_gradient_accum, self.denom, self.max_radii2D)
+        else:
+            self._stats_torch(radii, vis, vgrad)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach() if loss is not None else torch.zeros((), device=dev)

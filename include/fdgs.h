@@ -283,6 +283,40 @@ typedef struct {
 size_t fdgs_hexplane_features_workspace_bytes(const fdgs_deform_params* p, int32_t num_points);
 int fdgs_hexplane_features(const fdgs_hexplane_features_args* a, void* stream);
 
+/* ---- L1 image loss: scale * mean |a - b| over n floats (src/model/losses.py:7-8, called at
+ * src/runner/fdgs_trainer.py:495) and its gradient w.r.t. a.  Two launches forward, one backward. */
+typedef struct {
+    int64_t n;
+    const float* a;                  /* [n] rendered image(s)                       */
+    const float* b;                  /* [n] ground truth                            */
+    float scale;                     /* multiplies the mean (share of this view in a batch loss) */
+    float* loss;                     /* [1]                                         */
+    float* partial;                  /* [fdgs_l1_loss_partials(n)] scratch          */
+} fdgs_l1_fwd_args;
+typedef struct {
+    int64_t n;
+    const float* a; const float* b;
+    float scale;
+    const float* grad_loss;          /* [1] device scalar: dL/d(loss)               */
+    float* grad_a;                   /* [n] = grad_loss * scale / n * sign(a - b)   */
+} fdgs_l1_bwd_args;
+size_t fdgs_l1_loss_partials(int64_t n);
+int fdgs_l1_loss_fwd(const fdgs_l1_fwd_args* a, void* stream);
+int fdgs_l1_loss_bwd(const fdgs_l1_bwd_args* a, void* stream);
+
+/* ---- densification statistics of one iteration (src/runner/fdgs_trainer.py:181-182,
+ * src/model/gaussian_model.py:182-184): for every Gaussian with radii > 0,
+ * max_radii2D = max(max_radii2D, radii), xyz_gradient_accum += |viewspace_grad.xy|, denom += 1. */
+typedef struct {
+    int32_t num_points;
+    const int32_t* radii;            /* [N] (max over the views of the batch)       */
+    const float* viewspace_grad;     /* [N,3] gradient of the 2-D means (summed over the views) */
+    float* max_radii2D;              /* [N] or NULL                                 */
+    float* xyz_gradient_accum;       /* [N] (the reference's [N,1])                 */
+    float* denom;                    /* [N]                                         */
+} fdgs_densify_stats_args;
+int fdgs_densify_stats(const fdgs_densify_stats_args* a, void* stream);
+
 /* ---- Adam ------------------------------------------------------------------------------------
  * One step of torch.optim.Adam (no weight decay, no amsgrad) over up to 48 tensors in one launch:
  * the optimizer the reference builds at src/runner/fdgs_trainer.py:262-274 (eps 1e-15, one learning

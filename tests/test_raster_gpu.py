@@ -222,3 +222,39 @@ def test_fused_adam_matches_torch():
         for key in ("exp_avg", "exp_avg_sq"):      # max-norm relative: single elements cancel to near zero
             x, y = ref.state[a][key], our.state[b][key]
             assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max()), key
+
+
+def test_l1_loss_and_densification_stats_match_torch():
+    """fdgs.losses: scale * mean|a - b| with its gradient (src/model/losses.py:7-8) and the statistics update of
+    src/runner/fdgs_trainer.py:181-182 against the PyTorch expressions; sizes that exercise the 16-byte path,
+    the tail, and a non-contiguous input."""
+    from fdgs import losses
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    for shape in ((3, 1014, 1352), (3, 37, 53), (1, 5)):
+        a = torch.randn(shape, generator=gen).to(dev).requires_grad_(True)
+        b = torch.randn(shape, generator=gen).to(dev)
+        b.view(-1)[::7] = a.detach().view(-1)[::7]          # exact ties: sign 0
+        a2 = a.detach().clone().requires_grad_(True)
+        got = losses.l1_loss(a, b, 0.125) * 3.0
+        ref = torch.abs(a2 - b).mean() * 0.125 * 3.0
+        got.backward(); ref.backward()
+        assert abs(float(got) - float(ref)) <= 2e-6 * abs(float(ref))
+        assert torch.equal(a.grad == 0, a2.grad == 0)
+        assert float((a.grad - a2.grad).abs().max()) <= 1e-6 * float(a2.grad.abs().max())
+    at = torch.randn(64, 48, generator=gen).to(dev).t()     # non-contiguous view
+    assert abs(float(losses.l1_loss(at, torch.zeros_like(at))) - float(at.abs().mean())) <= 1e-6
+
+    n = 10007
+    radii = torch.randint(-1, 40, (n,), generator=gen).to(dev).to(torch.int32)
+    vgrad = torch.randn(n, 3, generator=gen).to(dev)
+    acc = torch.rand(n, 1, generator=gen).to(dev); den = torch.rand(n, 1, generator=gen).to(dev).round()
+    mx = (torch.rand(n, generator=gen) * 30).to(dev)
+    acc_r, den_r, mx_r = acc.clone(), den.clone(), mx.clone()
+    vis = radii > 0
+    mx_r[vis] = torch.max(mx_r[vis], radii[vis].float())
+    acc_r[vis] += torch.norm(vgrad[vis, :2], dim=-1, keepdim=True)
+    den_r[vis] += 1
+    losses.add_densification_stats(radii, vgrad, acc, den, mx)
+    assert torch.equal(mx, mx_r) and torch.equal(den, den_r)
+    assert float((acc - acc_r).abs().max()) <= 1e-6
