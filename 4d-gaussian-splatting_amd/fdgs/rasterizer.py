@@ -35,6 +35,20 @@ class GaussianRasterizationSettings(NamedTuple):
 
 LAST_NUM_RENDERED = 0     # tile-list length R of the most recent forward (bench bookkeeping)
 
+# Capacity of the R-sized buffers (keys, values, sort workspace).  R changes from view to view and from step
+# to step; sizing the buffers to R exactly makes the caching allocator see a new size almost every call, and
+# a size it has no block for costs a device allocation (tens of milliseconds here).  The capacity is therefore
+# R rounded up to a quarter-octave bucket and never shrinks within the process.
+_LIST_CAPACITY = 0
+
+
+def _list_capacity(R):
+    global _LIST_CAPACITY
+    if R > _LIST_CAPACITY:
+        step = 1 << max(R.bit_length() - 3, 10)
+        _LIST_CAPACITY = (R + step - 1) // step * step
+    return _LIST_CAPACITY
+
 
 def _f32c(t):
     if t.requires_grad:
@@ -79,12 +93,13 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     st.num_rendered = R
     global LAST_NUM_RENDERED
     LAST_NUM_RENDERED = R
-    keys_a = torch.empty(max(R, 1), device=dev, dtype=torch.int64)
-    vals_a = torch.empty(max(R, 1), device=dev, dtype=torch.int32)
-    st.keys_sorted = torch.empty(max(R, 1), device=dev, dtype=torch.int64)
-    st.vals_sorted = torch.empty(max(R, 1), device=dev, dtype=torch.int32)
+    cap = _list_capacity(max(R, 1))
+    keys_a = torch.empty(cap, device=dev, dtype=torch.int64)
+    vals_a = torch.empty(cap, device=dev, dtype=torch.int32)
+    st.keys_sorted = torch.empty(cap, device=dev, dtype=torch.int64)
+    st.vals_sorted = torch.empty(cap, device=dev, dtype=torch.int32)
     st.ranges = torch.empty(gx * gy, 2, device=dev, dtype=torch.int32)
-    ws_bytes = lib.fdgs_raster_sort_workspace_bytes(R)
+    ws_bytes = max(lib.fdgs_raster_sort_workspace_bytes(cap), lib.fdgs_raster_sort_workspace_bytes(R))
     sort_ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
     b = _lib.BinSortArgs(N, W, H, R, ptr(st.geom), ptr(st.point_offsets), ptr(keys_a), ptr(vals_a),
                          ptr(st.keys_sorted), ptr(st.vals_sorted), ptr(st.ranges), ptr(sort_ws), ws_bytes)

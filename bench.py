@@ -11,6 +11,7 @@ global batch is N views, one per rank (weak scaling), gradients and statistics
 are all-reduced over RCCL.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import math
 import os
@@ -28,8 +29,9 @@ import torch.distributed as dist
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=25,
+                    help="untimed steps; the default walks all 20 training views once so that buffer sizes settle")
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--width", type=int, default=1352)
     ap.add_argument("--height", type=int, default=1014)
@@ -158,6 +160,11 @@ def main():
     for i in range(args.warmup):
         step(batch(i))
     sync()
+    # a generation-2 collection of the cyclic garbage collector walks every live Python object (about 45 ms in a
+    # process with torch loaded, more than ten training steps); the steps themselves create no cycles, so
+    # everything alive after set-up is moved out of the collector's reach
+    gc.collect()
+    gc.freeze()
     with torch.no_grad():       # visible Gaussians of the first training view (recorded, not timed)
         visible = int((render(train_cams[rank % len(train_cams)], g, deforms, bg)["radii"] > 0).sum())
     _lib.PROFILE = {}
