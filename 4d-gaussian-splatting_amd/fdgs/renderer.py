@@ -25,11 +25,8 @@ def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifi
     means3D = pc.get_xyz
     dev = means3D.device
     # gradient carrier for the 2-D means (gaussian_renderer/__init__.py:27-31)
-    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=dev) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # a leaf, so .grad is kept without retain_grad() and without the reference's "+ 0" launch
+    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=dev)
 
     if cam_type != "PanopticSports":
         tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
