@@ -4,10 +4,39 @@
 // HBM-bound (reads 59 input floats + two 48-byte records, writes 62 floats).
 #include "fdgs_common.h"
 
+#define PBWD_SH_STRIDE 49                       // floats per Gaussian row of the LDS tile: odd, so rows do not share banks
+
+// Copies the workgroup's [rows][48] block between memory and the padded LDS tile with 16-byte accesses
+// (a thread's own 48 floats are 192 bytes apart from its neighbour's: direct per-thread accesses would touch 64
+// cache lines per instruction).
+template <bool TO_LDS>
+__device__ __forceinline__ void sh_tile_copy(float* __restrict__ tile, float* __restrict__ mem, int rows) {
+    const int n4 = rows * 12;
+    for (int j = threadIdx.x; j < n4; j += 256) {
+        const int row = j / 12, c4 = j - row * 12;
+        float* t = tile + row * PBWD_SH_STRIDE + 4 * c4;
+        float4* m = reinterpret_cast<float4*>(mem) + j;
+        if (TO_LDS) {
+            const float4 v = *m;
+            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        } else {
+            *m = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.num_points) return;
+    __shared__ float sh_tile[256 * PBWD_SH_STRIDE];
+    const int first = blockIdx.x * 256;
+    const int rows = min(256, a.num_points - first);
+    const bool inb = (int)threadIdx.x < rows;
+    const int i = first + (inb ? (int)threadIdx.x : 0);
+    const bool use_sh = a.colors_precomp == nullptr, use_cov = a.cov3D_precomp != nullptr;
+    if (use_sh) {                                   // SH coefficients in; the same rows carry dL/dSH out
+        sh_tile_copy<true>(sh_tile, const_cast<float*>(a.shs) + (size_t)first * 48, rows);
+        __syncthreads();
+    }
     const float4* __restrict__ geom4 = reinterpret_cast<const float4*>(a.geom) + 3 * (size_t)i;
     const float4* __restrict__ dg4 = reinterpret_cast<const float4*>(a.dL_dgeom) + 3 * (size_t)i;
     const float4 g2 = geom4[2];
@@ -17,13 +46,12 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
     float dmean[3] = {0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dm2x = 0.f, dm2y = 0.f;
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcolor[3] = {0.f, 0.f, 0.f};
-    const bool use_sh = a.colors_precomp == nullptr, use_cov = a.cov3D_precomp != nullptr;
-    float* dsh = use_sh ? a.dL_dshs + (size_t)i * 48 : nullptr;
+    float* dsh = sh_tile + threadIdx.x * PBWD_SH_STRIDE;      // this thread's row: read as SH, overwritten with dL/dSH
 
     if (radius <= 0) {
         if (use_sh) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) reinterpret_cast<float4*>(dsh)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 48; ++k) dsh[k] = 0.f;
         }
     } else {
         const float4 d0 = dg4[0], d1 = dg4[1], d2 = dg4[2];
@@ -46,7 +74,7 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             if (clampmask & (1 << c)) gcol[c] = 0.f;
-        const float* __restrict__ sh = a.shs + (size_t)i * 48;
+        const float* sh = dsh;
         float basis[16], bdx[16], bdy[16], bdz[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) { basis[k] = 0.f; bdx[k] = 0.f; bdy[k] = 0.f; bdz[k] = 0.f; }
@@ -90,8 +118,8 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
             float dot = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                dsh[3 * k + c] = basis[k] * gcol[c];
                 dot += sh[3 * k + c] * gcol[c];
+                dsh[3 * k + c] = basis[k] * gcol[c];
             }
             gux += bdx[k] * dot; guy += bdy[k] * dot; guz += bdz[k] * dot;
         }
@@ -239,6 +267,11 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
         dmean[1] += gphx * P[4] + gphy * P[5] + gphw * P[7];
         dmean[2] += gphx * P[8] + gphy * P[9] + gphw * P[11];
     }
+    if (use_sh) {
+        __syncthreads();
+        sh_tile_copy<false>(sh_tile, a.dL_dshs + (size_t)first * 48, rows);
+    }
+    if (!inb) return;
 #pragma unroll
     for (int k = 0; k < 3; ++k) a.dL_dmeans3D[3 * i + k] = dmean[k];
     if (use_cov) {
