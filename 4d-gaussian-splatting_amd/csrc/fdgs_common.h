@@ -53,3 +53,24 @@ __device__ __forceinline__ void fdgs_tile_rect(float px, float py, float r, int 
     fy1 = (fy1 != fy1) ? 0.0f : fminf(fmaxf(fy1, 0.0f), (float)gy);
     x0 = (int)fx0; y0 = (int)fy0; x1 = (int)fx1; y1 = (int)fy1;
 }
+
+#define FDGS_SH_TILE_STRIDE 49                       // floats per Gaussian row of the LDS tile: odd, so rows do not share banks
+
+// Copies the workgroup's [rows][48] block between memory and the padded LDS tile with 16-byte accesses
+// (a thread's own 48 floats are 192 bytes apart from its neighbour's: direct per-thread accesses would touch 64
+// cache lines per instruction).
+template <bool TO_LDS>
+__device__ __forceinline__ void sh_tile_copy(float* __restrict__ tile, float* __restrict__ mem, int rows) {
+    const int n4 = rows * 12;
+    for (int j = threadIdx.x; j < n4; j += 256) {
+        const int row = j / 12, c4 = j - row * 12;
+        float* t = tile + row * FDGS_SH_TILE_STRIDE + 4 * c4;
+        float4* m = reinterpret_cast<float4*>(mem) + j;
+        if (TO_LDS) {
+            const float4 v = *m;
+            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        } else {
+            *m = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+}

@@ -4,30 +4,9 @@
 // HBM-bound (reads 59 input floats + two 48-byte records, writes 62 floats).
 #include "fdgs_common.h"
 
-#define PBWD_SH_STRIDE 49                       // floats per Gaussian row of the LDS tile: odd, so rows do not share banks
-
-// Copies the workgroup's [rows][48] block between memory and the padded LDS tile with 16-byte accesses
-// (a thread's own 48 floats are 192 bytes apart from its neighbour's: direct per-thread accesses would touch 64
-// cache lines per instruction).
-template <bool TO_LDS>
-__device__ __forceinline__ void sh_tile_copy(float* __restrict__ tile, float* __restrict__ mem, int rows) {
-    const int n4 = rows * 12;
-    for (int j = threadIdx.x; j < n4; j += 256) {
-        const int row = j / 12, c4 = j - row * 12;
-        float* t = tile + row * PBWD_SH_STRIDE + 4 * c4;
-        float4* m = reinterpret_cast<float4*>(mem) + j;
-        if (TO_LDS) {
-            const float4 v = *m;
-            t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-        } else {
-            *m = make_float4(t[0], t[1], t[2], t[3]);
-        }
-    }
-}
-
 __global__ void __launch_bounds__(256)
 preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
-    __shared__ float sh_tile[256 * PBWD_SH_STRIDE];
+    __shared__ float sh_tile[256 * FDGS_SH_TILE_STRIDE];
     const int first = blockIdx.x * 256;
     const int rows = min(256, a.num_points - first);
     const bool inb = (int)threadIdx.x < rows;
@@ -46,7 +25,7 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
     float dmean[3] = {0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dm2x = 0.f, dm2y = 0.f;
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dcolor[3] = {0.f, 0.f, 0.f};
-    float* dsh = sh_tile + threadIdx.x * PBWD_SH_STRIDE;      // this thread's row: read as SH, overwritten with dL/dSH
+    float* dsh = sh_tile + threadIdx.x * FDGS_SH_TILE_STRIDE;      // this thread's row: read as SH, overwritten with dL/dSH
 
     if (radius <= 0) {
         if (use_sh) {

@@ -16,8 +16,15 @@
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.num_points) return;
+    __shared__ float sh_tile[256 * FDGS_SH_TILE_STRIDE];
+    const int first = blockIdx.x * 256;
+    const int rows = min(256, a.num_points - first);
+    if (!a.colors_precomp) {                        // the workgroup's SH coefficients, read with 16-byte accesses
+        sh_tile_copy<true>(sh_tile, const_cast<float*>(a.shs) + (size_t)first * 48, rows);
+        __syncthreads();
+    }
+    if ((int)threadIdx.x >= rows) return;
+    const int i = first + threadIdx.x;
     const int W = a.image_width, H = a.image_height;
     const int gx = (W + FDGS_TILE - 1) / FDGS_TILE, gy = (H + FDGS_TILE - 1) / FDGS_TILE;
     const float* __restrict__ V = a.viewmatrix;
@@ -135,7 +142,7 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
             const float ddx = x - a.campos[0], ddy = y - a.campos[1], ddz = z - a.campos[2];
             const float nrm = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
             const float ux = ddx / nrm, uy = ddy / nrm, uz = ddz / nrm;
-            const float* __restrict__ sh = a.shs + (size_t)i * 48;
+            const float* sh = sh_tile + threadIdx.x * FDGS_SH_TILE_STRIDE;
             float res[3];
 #pragma unroll
             for (int c = 0; c < 3; ++c) res[c] = SH_C0 * sh[c];
