@@ -136,6 +136,20 @@ __device__ __forceinline__ Bilinear make_bilinear(float ca, float cb, int Wd, in
     return b;
 }
 
+// one coordinate axis of a bilinear lookup: lower texel, step to the upper one (0 at the border), fraction,
+// and whether the coordinate is strictly inside (same arithmetic as make_bilinear)
+struct AxisLookup { int i0, d; float f; bool in; };
+__device__ __forceinline__ AxisLookup make_axis(float c, int size) {
+    AxisLookup a;
+    float x;
+    unnorm_clip(c, size, x, a.in);
+    const float x0f = floorf(x);
+    a.i0 = (int)x0f;
+    a.d = min(a.i0 + 1, size - 1) - a.i0;
+    a.f = x - x0f;
+    return a;
+}
+
 // normalised 4-D coordinate of a point: (xyz - aabb[0]) * (2/(aabb[1]-aabb[0])) - 1, then raw time
 // (src/model/hexplane.py:14-17,185-186).
 __device__ __forceinline__ void point_coords(const float* __restrict__ xyz, const float* __restrict__ aabb,

@@ -284,10 +284,15 @@ __device__ __forceinline__ floatx16 bias_block(const float* __restrict__ padded,
 }
 
 // ---------------------------------------------------------------------------
-// Forward, kernel 1: HexPlane features at full occupancy.  Lane (c, h) of a wave
-// interpolates level h for point c of a 32-point group and writes its 16
-// features already split, in the B-operand order of the first Linear
-// (group G, chunk j, piece: 64 lanes x 16 bytes contiguous).
+// Forward, kernel 1: HexPlane features at full occupancy.  Gather phase: 16 lanes
+// per point (lane = channel), the two levels in turn, so that every texel access
+// of a point is one contiguous 64-byte segment (four segments per wave
+// instruction; with one lane per point an instruction touches 64 of them and the
+// kernel is bound by the cache-line rate of the vector memory path).  The
+// features go through an LDS tile; in the second phase lane (c, h) of a wave
+// reads the 16 features of level h of point c of a 32-point group and writes
+// them already split, in the B-operand order of the first Linear (group G,
+// chunk j, piece: 64 lanes x 16 bytes contiguous).
 // ---------------------------------------------------------------------------
 struct HexFeatSK {
     int n;
@@ -298,17 +303,65 @@ struct HexFeatSK {
     float* feat_f32;                     // optional [n,32]
 };
 
+#define HF_PTS 128                       // points per workgroup (4 waves x 32)
+#define HF_STRIDE 36                     // floats per point row of the tile: 32 + 4, rows of 16 lanes hit 64 distinct banks
+
 __global__ void __launch_bounds__(256)
 hexplane_features_split_kernel(HexFeatSK a) {
+    __shared__ __attribute__((aligned(16))) float tile[HF_PTS * HF_STRIDE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const int ch = lane & 15, sub = lane >> 4;
+        const int p0 = blockIdx.x * HF_PTS;
+#pragma unroll 1
+        for (int ib = wave * 4; ib < HF_PTS; ib += 16) {
+            const int pl = ib + sub;
+            const int p = min(p0 + pl, a.n - 1);
+            float co[4], sc3[3];
+            point_coords(a.xyz, a.aabb, a.time, a.time_scalar, p, co, sc3);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                 // both levels' 48 loads in flight
+                AxisLookup axl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) axl[q] = make_axis(co[q], h ? a.ps.res[1][q] : a.ps.res[0][q]);
+                float tex[6][4];
+#pragma unroll
+                for (int ci = 0; ci < 6; ++ci) {
+                    const int ax = plane_a(ci), bx = plane_b(ci);
+                    const int Wd = h ? a.ps.res[1][ax] : a.ps.res[0][ax];
+                    const float* __restrict__ pl_ = (h ? a.ps.pl[1][ci] : a.ps.pl[0][ci]) + ch;
+                    const int o00 = axl[bx].i0 * Wd + axl[ax].i0;
+                    const int oy = axl[bx].d * Wd;
+                    tex[ci][0] = pl_[(size_t)o00 * DF];
+                    tex[ci][1] = pl_[(size_t)(o00 + axl[ax].d) * DF];
+                    tex[ci][2] = pl_[(size_t)(o00 + oy) * DF];
+                    tex[ci][3] = pl_[(size_t)(o00 + oy + axl[ax].d) * DF];
+                }
+                float feat = 1.0f;
+#pragma unroll
+                for (int ci = 0; ci < 6; ++ci) {
+                    const float fx = axl[plane_a(ci)].f, fy = axl[plane_b(ci)].f;
+                    feat *= tex[ci][0] * ((1.0f - fx) * (1.0f - fy)) + tex[ci][1] * (fx * (1.0f - fy)) +
+                            tex[ci][2] * ((1.0f - fx) * fy) + tex[ci][3] * (fx * fy);
+                }
+                tile[pl * HF_STRIDE + 16 * h + ch] = feat;
+            }
+        }
+    }
+    __syncthreads();
     const int c = lane & 31, h = lane >> 5;
     const int G = blockIdx.x * 4 + wave;
     if (G * 32 >= a.n) return;
     const int p = G * 32 + c;
-    const int pc = min(p, a.n - 1);
-    float co[4], sc3[3], feat[DF];
-    point_coords(a.xyz, a.aabb, a.time, a.time_scalar, pc, co, sc3);
-    level_features(a.ps, h, co, feat, nullptr);
+    float feat[DF];
+    {
+        const float4* row = reinterpret_cast<const float4*>(tile + (wave * 32 + c) * HF_STRIDE + 16 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = row[q];
+            feat[4 * q] = t.x; feat[4 * q + 1] = t.y; feat[4 * q + 2] = t.z; feat[4 * q + 3] = t.w;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const Split3 s = split8<false>(feat + 8 * j);

@@ -140,20 +140,6 @@ struct HexBrickK {
     const int* perm; const int* work; const int* work_count;
 };
 
-// one coordinate axis of a bilinear lookup: lower texel, step to the upper one (0 at the border), fraction,
-// and whether the coordinate is strictly inside (same arithmetic as make_bilinear)
-struct AxisLookup { int i0, d; float f; bool in; };
-__device__ __forceinline__ AxisLookup make_axis(float c, int size) {
-    AxisLookup a;
-    float x;
-    unnorm_clip(c, size, x, a.in);
-    const float x0f = floorf(x);
-    a.i0 = (int)x0f;
-    a.d = min(a.i0 + 1, size - 1) - a.i0;
-    a.f = x - x0f;
-    return a;
-}
-
 __global__ void __launch_bounds__(BRICK_THREADS)
 hexplane_bwd_brick_kernel(HexBrickK k, int lds_floats) {
     extern __shared__ __attribute__((aligned(16))) double brick_lds[];
