@@ -125,3 +125,95 @@ extern "C" int fdgs_densify_stats(const fdgs_densify_stats_args* a, void* stream
     FDGS_CHECK_LAUNCH();
     return FDGS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Grid regulariser of the deformation field (src/model/deformation_wrapper.py:52-92 with
+// src/utils/plane_utils.py:3-9): for every plane [C][h][w] the mean squared second difference along h,
+// weighted, plus for the time planes the weighted mean |1 - t|.  One thread per element computes its loss
+// terms and, if asked, the complete gradient of that element (the second difference is a 3-tap stencil,
+// its adjoint a 5-tap one: five loads along h).  In PyTorch this is about 100 launches forward and 150
+// backward per iteration.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+plane_reg_kernel(fdgs_plane_reg_args a, int blocks_per_plane) {
+    __shared__ float sh[4];
+    const int pi = blockIdx.x / blocks_per_plane;
+    const int bx = blockIdx.x - pi * blocks_per_plane;
+    // uniform selection without dynamic indexing of the argument arrays
+    const float* __restrict__ t = a.plane[0]; float* g = a.grad[0];
+    int h = a.h[0], w = a.w[0]; float ws = a.w_smooth[0], wl = a.w_l1[0];
+#pragma unroll
+    for (int i = 1; i < FDGS_REG_MAX_PLANES; ++i)
+        if (pi == i) { t = a.plane[i]; g = a.grad[i]; h = a.h[i]; w = a.w[i]; ws = a.w_smooth[i]; wl = a.w_l1[i]; }
+    const int hw = h * w, total = a.channels * hw;
+    const float ms = h > 2 ? ws / ((float)a.channels * (float)(h - 2) * (float)w) : 0.0f;   // weight / count of the mean
+    const float ml = wl / (float)total;
+    const float gs = a.grad_scale ? a.grad_scale[0] : 1.0f;
+    float loss = 0.0f;
+    for (int idx = bx * 256 + threadIdx.x; idx < total; idx += blocks_per_plane * 256) {
+        const int c = idx / hw, r = idx - c * hw;
+        const int y = r / w;
+        const float* col = t + idx;                       // element (c, y, x); neighbours along h are w apart
+        const float t0 = col[0];
+        const float tm2 = y >= 2 ? col[-2 * w] : 0.0f, tm1 = y >= 1 ? col[-w] : 0.0f;
+        const float tp1 = y + 1 < h ? col[w] : 0.0f, tp2 = y + 2 < h ? col[2 * w] : 0.0f;
+        // second differences that contain this element: d2(i) = (t[i+2] - t[i+1]) - (t[i+1] - t[i]), 0 <= i <= h-3
+        const float d_y = (y + 2 < h) ? (tp2 - tp1) - (tp1 - t0) : 0.0f;              // i = y
+        const float d_y1 = (y >= 1 && y + 1 < h) ? (tp1 - t0) - (t0 - tm1) : 0.0f;    // i = y - 1
+        const float d_y2 = (y >= 2) ? (t0 - tm1) - (tm1 - tm2) : 0.0f;                // i = y - 2
+        const float one_minus = 1.0f - t0;
+        loss += ms * (d_y * d_y) + ml * fabsf(one_minus);
+        if (g) {
+            const float gsm = 2.0f * (d_y - 2.0f * d_y1 + d_y2);
+            const float gl1 = one_minus > 0.0f ? -1.0f : (one_minus < 0.0f ? 1.0f : 0.0f);
+            const float v = gs * (ms * gsm + ml * gl1);
+            if (a.accumulate) g[idx] += v; else g[idx] = v;
+        }
+    }
+    if (a.loss_partial) {
+        loss = block_sum_256(loss, sh);
+        if (threadIdx.x == 0) a.loss_partial[blockIdx.x] = loss;
+    }
+}
+
+__global__ void __launch_bounds__(L1_THREADS)
+plane_reg_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ double shd[L1_THREADS];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += L1_THREADS) s += (double)partial[i];
+    shd[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = L1_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)shd[0];
+}
+
+#define REG_BLOCKS_PER_PLANE 64
+
+extern "C" size_t fdgs_plane_reg_partials(int32_t num_planes) {
+    return (size_t)(num_planes > 0 ? num_planes : 1) * REG_BLOCKS_PER_PLANE;
+}
+
+extern "C" int fdgs_plane_regulation(const fdgs_plane_reg_args* a, void* stream) {
+    if (!a || a->num_planes < 1 || a->num_planes > FDGS_REG_MAX_PLANES || a->channels < 1) return FDGS_EINVAL;
+    if ((a->loss == nullptr) != (a->loss_partial == nullptr)) return FDGS_EINVAL;
+    bool any_grad = false;
+    for (int i = 0; i < a->num_planes; ++i) {
+        if (!a->plane[i] || a->h[i] < 1 || a->w[i] < 1) return FDGS_EINVAL;
+        if ((long long)a->channels * a->h[i] * a->w[i] > 0x7fffffffLL) return FDGS_EINVAL;
+        any_grad = any_grad || a->grad[i];
+    }
+    if (!a->loss && !any_grad) return FDGS_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(plane_reg_kernel, dim3(a->num_planes * REG_BLOCKS_PER_PLANE), dim3(256), 0, s, *a,
+                       REG_BLOCKS_PER_PLANE);
+    FDGS_CHECK_LAUNCH();
+    if (a->loss) {
+        hipLaunchKernelGGL(plane_reg_final_kernel, dim3(1), dim3(L1_THREADS), 0, s, a->loss_partial,
+                           a->num_planes * REG_BLOCKS_PER_PLANE, a->loss);
+        FDGS_CHECK_LAUNCH();
+    }
+    return FDGS_OK;
+}

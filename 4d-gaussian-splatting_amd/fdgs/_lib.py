@@ -114,6 +114,17 @@ class DensifyStatsArgs(C.Structure):
                 ("xyz_gradient_accum", c_p), ("denom", c_p)]
 
 
+REG_MAX_PLANES = 12
+
+
+class PlaneRegArgs(C.Structure):
+    _fields_ = [("num_planes", c_i32), ("channels", c_i32), ("plane", c_p * REG_MAX_PLANES),
+                ("h", c_i32 * REG_MAX_PLANES), ("w", c_i32 * REG_MAX_PLANES),
+                ("w_smooth", c_f * REG_MAX_PLANES), ("w_l1", c_f * REG_MAX_PLANES),
+                ("grad", c_p * REG_MAX_PLANES), ("grad_scale", c_p), ("accumulate", c_i32),
+                ("loss", c_p), ("loss_partial", c_p)]
+
+
 ADAM_MAX_TENSORS = 48
 
 
@@ -144,11 +155,13 @@ SYMBOLS = {
     "fdgs_l1_loss_fwd": (C.c_int, [C.POINTER(L1FwdArgs), c_p]),
     "fdgs_l1_loss_bwd": (C.c_int, [C.POINTER(L1BwdArgs), c_p]),
     "fdgs_densify_stats": (C.c_int, [C.POINTER(DensifyStatsArgs), c_p]),
+    "fdgs_plane_reg_partials": (c_sz, [c_i32]),
+    "fdgs_plane_regulation": (C.c_int, [C.POINTER(PlaneRegArgs), c_p]),
     "fdgs_adam_step": (C.c_int, [C.POINTER(AdamArgs), c_p]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 def _load():

@@ -60,25 +60,25 @@ class GradBucket:
         if not self.params:
             return
         self._ensure(self.params[0].device)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        # gather and scatter with one concatenation and one multi-tensor copy (not a launch pair per tensor)
+        sizes = [p.numel() for p in self.params]
+        views = self.flat.split_with_sizes(sizes)
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        if missing:
+            for i in missing:
+                views[i].zero_()
+            present = [i for i, p in enumerate(self.params) if p.grad is not None]
+            if present:
+                torch._foreach_copy_([views[i] for i in present], [self.params[i].grad.reshape(-1) for i in present])
+        else:
+            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
         if is_dist():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            g = self.flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
+        for i in missing:
+            self.params[i].grad = views[i].view_as(self.params[i]).clone()
+        have = [i for i in range(len(self.params)) if i not in set(missing)]
+        if have:
+            torch._foreach_copy_([self.params[i].grad for i in have], [views[i].view_as(self.params[i]) for i in have])
 
 
 def reduce_densification_stats(radii, visibility, viewspace_grad, group=None):

@@ -57,3 +57,108 @@ def add_densification_stats(radii, viewspace_grad, xyz_gradient_accum, denom, ma
             raise ValueError("the accumulators must be contiguous float32 (they are updated in place)")
     _lib.call("fdgs_densify_stats", _lib.DensifyStatsArgs(n, ptr(r), ptr(g), ptr(max_radii2D), ptr(xyz_gradient_accum),
                                                            ptr(denom)))
+
+
+# ---- grid regulariser (src/model/deformation_wrapper.py:52-92) ---------------------------------------------
+
+_TIME_PLANES = (2, 4, 5)       # planes with a time axis, in itertools.combinations(range(4), 2) order
+
+
+def _reg_args(planes_per_level, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
+    planes = []
+    a = _lib.PlaneRegArgs()
+    k = 0
+    for grids in planes_per_level:
+        if len(grids) == 3:                     # a static (3-D) field has no regularised planes (:58-59, 69-70)
+            continue
+        for ci, p in enumerate(grids):
+            if k >= _lib.REG_MAX_PLANES:
+                raise ValueError("at most 12 planes per call")
+            t = p.detach()
+            if t.dim() != 4 or t.shape[0] != 1 or t.dtype is not torch.float32 or not t.is_contiguous():
+                raise ValueError("planes must be contiguous float32 [1, C, h, w]")
+            if k and t.shape[1] != a.channels:
+                raise ValueError("all planes must have the same channel count")
+            a.channels = t.shape[1]
+            a.plane[k] = t.data_ptr(); a.h[k] = t.shape[2]; a.w[k] = t.shape[3]
+            is_time = ci in _TIME_PLANES
+            a.w_smooth[k] = time_smoothness_weight if is_time else plane_tv_weight
+            a.w_l1[k] = l1_time_planes_weight if is_time else 0.0
+            planes.append(p)
+            k += 1
+    a.num_planes = k
+    return a, planes
+
+
+class _PlaneRegulation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weights, levels, *flat_planes):
+        it = iter(flat_planes)
+        per_level = [[next(it) for _ in range(n)] for n in levels]
+        _lib.require_gpu(*flat_planes)
+        a, planes = _reg_args(per_level, *weights)
+        dev = flat_planes[0].device
+        loss = torch.zeros((), device=dev, dtype=torch.float32)
+        if a.num_planes:
+            partial = torch.empty(lib.fdgs_plane_reg_partials(a.num_planes), device=dev, dtype=torch.float32)
+            a.loss, a.loss_partial = loss.data_ptr(), partial.data_ptr()
+            _lib.call("fdgs_plane_regulation", a)
+        ctx.weights, ctx.levels = weights, levels
+        ctx.save_for_backward(*flat_planes)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        flat_planes = ctx.saved_tensors
+        it = iter(flat_planes)
+        per_level = [[next(it) for _ in range(n)] for n in ctx.levels]
+        a, planes = _reg_args(per_level, *ctx.weights)
+        grads = {}
+        if a.num_planes:
+            g = grad_loss if (grad_loss.dtype is torch.float32 and grad_loss.is_contiguous()) else \
+                grad_loss.to(torch.float32).contiguous()
+            flat = torch.empty(sum(p.numel() for p in planes), device=g.device, dtype=torch.float32)
+            for k, (p, piece) in enumerate(zip(planes, flat.split_with_sizes([p.numel() for p in planes]))):
+                grads[id(p)] = piece.view(p.shape)
+                a.grad[k] = piece.data_ptr()
+            a.grad_scale = g.data_ptr()
+            _lib.call("fdgs_plane_regulation", a)
+        return (None, None) + tuple(grads.get(id(p)) for p in flat_planes)
+
+
+def compute_regulation(deformation_fields, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight):
+    """DeformationWrapper.compute_regulation for a DeformationFields module (same argument order): a scalar
+    with autograd, two launches forward and one backward for all planes."""
+    grids = deformation_fields.deformation_net.grid.grids
+    flat = [p for gp in grids for p in gp]
+    return _PlaneRegulation.apply((float(time_smoothness_weight), float(l1_time_planes_weight), float(plane_tv_weight)),
+                                  tuple(len(gp) for gp in grids), *flat)
+
+
+@torch.no_grad()
+def add_regulation_grad_(deformation_fields, time_smoothness_weight, l1_time_planes_weight, plane_tv_weight,
+                         want_loss=True):
+    """What `loss += compute_regulation(...)` before `loss.backward()` does to the planes' .grad, done after the
+    backward in one launch: the regulariser's gradient is added in place to the existing .grad tensors (no
+    twelve separate accumulation launches).  Returns the regulariser's value (or None)."""
+    grids = deformation_fields.deformation_net.grid.grids
+    a, planes = _reg_args([list(gp) for gp in grids], float(time_smoothness_weight), float(l1_time_planes_weight),
+                          float(plane_tv_weight))
+    if not a.num_planes:
+        return None
+    _lib.require_gpu(*planes)
+    for k, p in enumerate(planes):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        if not (p.grad.is_contiguous() and p.grad.dtype is torch.float32):
+            raise ValueError("plane gradients must be contiguous float32")
+        a.grad[k] = p.grad.data_ptr()
+    a.accumulate = 1
+    loss = None
+    if want_loss:
+        dev = planes[0].device
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        partial = torch.empty(lib.fdgs_plane_reg_partials(a.num_planes), device=dev, dtype=torch.float32)
+        a.loss, a.loss_partial = loss.data_ptr(), partial.data_ptr()
+    _lib.call("fdgs_plane_regulation", a)
+    return loss

@@ -19,8 +19,14 @@ class DeformHolder:
 
 
 class TrainStep:
-    def __init__(self, gaussians, deforms, background, lr_scale=1.0, stage="fine", fused_adam=True):
+    # time_smoothness_weight, l1_time_planes, plane_tv_weight of configs/train/dynerf.yaml:53-55
+    DYNERF_REGULATION = (0.001, 0.0001, 0.0002)
+
+    def __init__(self, gaussians, deforms, background, lr_scale=1.0, stage="fine", fused_adam=True,
+                 regulation=DYNERF_REGULATION):
         self.g, self.deforms, self.bg, self.stage = gaussians, deforms, background, stage
+        # fdgs_trainer.py:133-135: the grid regulariser joins the loss in the fine stage when its weight is set
+        self.regulation = tuple(regulation) if (regulation and "fine" in stage and regulation[0] != 0) else None
         df = deforms.deformation_fields
         groups = [   # configs/train/dynerf.yaml:23-35, fdgs_trainer.py:262-272
             {"params": [gaussians._xyz], "lr": 0.00016 * lr_scale, "name": "xyz"},
@@ -73,8 +79,20 @@ class TrainStep:
             radii_list.append(pkg["radii"])
             vis_list.append(pkg["visibility_filter"])
             vsp_list.append(pkg["viewspace_points"])
+        # fdgs_trainer.py:133-135.  A view-independent term: every rank takes 1/world of it and the gradient
+        # all-reduce (a sum) completes it.
+        reg = None
+        reg_w = None
+        if self.regulation is not None:
+            share = 1.0 / dp.rank_world()[1]
+            reg_w = tuple(w * share for w in self.regulation)
+            if not self.fused_tail and loss is not None:
+                loss = loss + losses.compute_regulation(self.deforms.deformation_fields, *reg_w)
         if loss is not None:
             loss.backward()
+        if reg_w is not None and self.fused_tail:
+            # same gradients as adding the term to the loss, written into the planes' .grad in one launch
+            reg = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
         n = self.g._xyz.shape[0]
         dev = self.g._xyz.device
         if len(views) == 1:
@@ -98,4 +116,5 @@ class TrainStep:
             self._stats_torch(radii, vis, vgrad)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
-        return loss.detach() if loss is not None else torch.zeros((), device=dev)
+        out = loss.detach() if loss is not None else torch.zeros((), device=dev)
+        return out if reg is None else out + reg

@@ -117,10 +117,14 @@ def cpu_baseline(args, g, net, cam, bg):
     t0 = time.time()
     torch.autograd.backward(mids, gmid)                            # preprocess + deformation backward, all points
     t_rest_b = time.time() - t0
-    est = t_def_f + t_pre + (t_blend_f + t_blend_b) / max(frac, 1e-9) + t_rest_b
-    measured = t_def_f + t_pre + t_blend_f + t_blend_b + t_rest_b
+    t0 = time.time()                                               # grid regulariser of the fine stage, fwd + bwd
+    from fdgs.train_step import TrainStep
+    deform_ref.compute_regulation(sd, *TrainStep.DYNERF_REGULATION).backward()
+    t_reg = time.time() - t0
+    est = t_def_f + t_pre + (t_blend_f + t_blend_b) / max(frac, 1e-9) + t_rest_b + t_reg
+    measured = t_def_f + t_pre + t_blend_f + t_blend_b + t_rest_b + t_reg
     return {"value": 1.0 / est, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": (f"deformation fwd+bwd and rasterizer preprocess/sort on all {N} points; blending fwd+bwd on "
+            "sample": (f"deformation fwd+bwd, grid regulariser and rasterizer preprocess/sort on all {N} points; blending fwd+bwd on "
                        f"every {args.cpu_tile_stride}th tile ({len(tiles)} of {gx * gy} tiles, {frac:.4f} of the "
                        f"tile-list entries), blending time divided by that fraction; measured {measured:.1f} s"),
             "seconds_measured": measured, "estimated_step_seconds": est}
@@ -246,7 +250,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DyNeRF-shaped synthetic scene, single-view training step "
-                                   "per GPU (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + Adam)",
+                                   "per GPU (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + L1 loss + grid regulariser + densification statistics + Adam)",
                        "gaussians": args.gaussians, "image": [args.width, args.height], "sh_degree": 3,
                        "global_batch_views": world, "views_per_gpu": 1, "visible_gaussians": visible,
                        "tile_list_entries": R,

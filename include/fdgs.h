@@ -317,6 +317,30 @@ typedef struct {
 } fdgs_densify_stats_args;
 int fdgs_densify_stats(const fdgs_densify_stats_args* a, void* stream);
 
+/* ---- grid regulariser of the deformation field: DeformationWrapper.compute_regulation
+ * (src/model/deformation_wrapper.py:52-92, compute_plane_smoothness of src/utils/plane_utils.py:3-9;
+ * added to the loss at src/runner/fdgs_trainer.py:133-135).  Per plane [channels][h][w] (the parameter
+ * layout): w_smooth * mean((second difference along h)^2) + w_l1 * mean|1 - t|.  The caller sets
+ * w_smooth = plane_tv_weight for the spatial planes (0, 1, 3), time_smoothness_weight for the time
+ * planes (2, 4, 5), and w_l1 = l1_time_planes_weight for the time planes, 0 otherwise.
+ * loss (optional) receives the sum over the planes; grad[i] (optional per plane) receives
+ * grad_scale * d(loss)/d(plane i), added to its contents when accumulate != 0. */
+#define FDGS_REG_MAX_PLANES 12
+typedef struct {
+    int32_t num_planes;
+    int32_t channels;
+    const float* plane[FDGS_REG_MAX_PLANES];
+    int32_t h[FDGS_REG_MAX_PLANES], w[FDGS_REG_MAX_PLANES];
+    float w_smooth[FDGS_REG_MAX_PLANES], w_l1[FDGS_REG_MAX_PLANES];
+    float* grad[FDGS_REG_MAX_PLANES];
+    const float* grad_scale;         /* [1] device scalar, or NULL for 1            */
+    int32_t accumulate;
+    float* loss;                     /* [1] or NULL                                 */
+    float* loss_partial;             /* [fdgs_plane_reg_partials(num_planes)] scratch, with loss */
+} fdgs_plane_reg_args;
+size_t fdgs_plane_reg_partials(int32_t num_planes);
+int fdgs_plane_regulation(const fdgs_plane_reg_args* a, void* stream);
+
 /* ---- Adam ------------------------------------------------------------------------------------
  * One step of torch.optim.Adam (no weight decay, no amsgrad) over up to 48 tensors in one launch:
  * the optimizer the reference builds at src/runner/fdgs_trainer.py:262-274 (eps 1e-15, one learning

@@ -152,3 +152,25 @@ def test_scalar_time_backward_matches_oracle(hex_bwd, monkeypatch):
     for name, g, r in zip(["xyz"] + tkeys, got, ref_g):
         r = torch.zeros_like(g.cpu()) if r is None else r
         assert _rel(g.cpu(), r) <= GRAD_TOL, (hex_bwd, name)
+
+
+@pytest.mark.parametrize("case", list(dc.CASES))
+def test_plane_regulation_vs_reference_golden(case):
+    """fdgs.losses.compute_regulation (autograd) and add_regulation_grad_ (in place after the backward) against
+    the reference's DeformationWrapper.compute_regulation on the golden parameters."""
+    from fdgs import losses
+    from test_oracle_deform import check_regulation_against_golden, REG_WEIGHTS
+    dev = torch.device("cuda:0")
+    net, sd = _module(case, dev)
+    planes = [p for gp in net.deformation_net.grid.grids for p in gp]
+    loss = losses.compute_regulation(net, *REG_WEIGHTS) * 2.0            # a non-unit upstream gradient
+    grads = torch.autograd.grad(loss, planes)
+    check_regulation_against_golden(case, float(loss) / 2.0, [g.cpu() / 2.0 for g in grads])
+    # in-place route: .grad holds something already, the regulariser's gradient is added to it
+    for p in planes:
+        p.grad = torch.zeros_like(p)
+    val = losses.add_regulation_grad_(net, *REG_WEIGHTS)
+    once = [p.grad.clone() for p in planes]
+    check_regulation_against_golden(case, float(val), [g.cpu() for g in once])
+    losses.add_regulation_grad_(net, *REG_WEIGHTS, want_loss=False)          # accumulates: x + x is exact
+    assert all(torch.equal(p.grad, 2.0 * g) for p, g in zip(planes, once))
