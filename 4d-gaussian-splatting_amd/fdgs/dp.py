@@ -23,6 +23,34 @@ def rank_world():
     return 0, 1
 
 
+def all_reduce_(t, op, group=None):
+    """In-place all-reduce.  RCCL ("nccl") takes device tensors as they are; with the gloo backend (CPU
+    rehearsals of the exchange step) a device tensor is staged through host memory here, explicitly."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+@torch.no_grad()
+def broadcast_parameters(params, src=0, group=None):
+    """Makes every rank's replica bit-identical to rank `src`'s (one flat broadcast)."""
+    params = list(params)
+    if not is_dist() or not params:
+        return
+    flat = torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params])
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        h = flat.cpu()
+        dist.broadcast(h, src=src, group=group)
+        flat.copy_(h)
+    else:
+        dist.broadcast(flat, src=src, group=group)
+    torch._foreach_copy_([p.data for p in params], [v.view_as(p) for p, v in
+                                                     zip(params, flat.split_with_sizes([p.numel() for p in params]))])
+
+
 def shard_views(views, rank=None, world=None):
     """Rank r takes views r, r+W, r+2W, ... of the global batch."""
     if rank is None:
@@ -73,7 +101,7 @@ class GradBucket:
         else:
             torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
         if is_dist():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            all_reduce_(self.flat, dist.ReduceOp.SUM, group)
         for i in missing:
             self.params[i].grad = views[i].view_as(self.params[i]).clone()
         have = [i for i in range(len(self.params)) if i not in set(missing)]
@@ -89,7 +117,7 @@ def reduce_densification_stats(radii, visibility, viewspace_grad, group=None):
     r = radii.contiguous()
     v = visibility.to(torch.uint8).contiguous()
     g = viewspace_grad.contiguous()
-    dist.all_reduce(r, op=dist.ReduceOp.MAX, group=group)
-    dist.all_reduce(v, op=dist.ReduceOp.MAX, group=group)
-    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    all_reduce_(r, dist.ReduceOp.MAX, group)
+    all_reduce_(v, dist.ReduceOp.MAX, group)
+    all_reduce_(g, dist.ReduceOp.SUM, group)
     return r, v.bool(), g

@@ -46,6 +46,7 @@ class TrainStep:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self.params = [p for grp in groups for p in grp["params"]]
         self.bucket = dp.GradBucket(self.params)
+        dp.broadcast_parameters(self.params)      # replicas start identical whatever the ranks' RNG state was
         n = gaussians._xyz.shape[0]
         dev = gaussians._xyz.device
         self.xyz_gradient_accum = torch.zeros(n, 1, device=dev)

@@ -50,6 +50,7 @@ def build_scene(args, dev):
     from fdgs.renderer import render
     from fdgs.train_step import DeformHolder
     g = ss.GaussianParams(args.gaussians, device=dev, scale_mult=args.scale_mult)
+    torch.manual_seed(ss.SEED)                # train.py:27: every rank builds the same replica
     net = DeformationFields(ss.DYNERF_NET_KWARGS)
     ss.perturb_deformation_(net)
     net = net.to(dev)

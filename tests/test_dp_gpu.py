@@ -1,0 +1,35 @@
+"""GPU: the view-parallel training step with two ranks (gloo rendezvous, both ranks on cuda:0, collectives
+staged through host memory) against the same global batch on one rank.  Parameters are frozen (the optimizer
+update is replaced by a recorder), so every step's gradients - data term, regulariser share, all-reduce -
+and the densification statistics must agree to rounding; with Adam's eps of 1e-15 a free-running comparison
+would amplify rounding-level sign noise of near-zero gradients into +-lr."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_two_ranks_match_one_rank(tmp_path):
+    worker = os.path.join(HERE, "dp_gpu_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", worker, str(tmp_path)]
+    r = subprocess.run(two, env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    r = subprocess.run([sys.executable, worker, str(tmp_path)], env=env, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    a0 = torch.load(tmp_path / "w2_r0.pt")
+    a1 = torch.load(tmp_path / "w2_r1.pt")
+    one = torch.load(tmp_path / "w1_r0.pt")
+    # replicas: rank 1 started from another RNG state and must have been overwritten by rank 0's parameters
+    assert torch.equal(a0["w"], a1["w"]) and torch.equal(a0["w"], one["w"])
+    for k in one:
+        assert torch.equal(a0[k], a1[k]), k                  # identical on both ranks after the exchange
+        ref = one[k].float()
+        assert float((a0[k].float() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12, k
+    assert float(one["denom"].sum()) > 0 and torch.equal(a0["denom"], one["denom"]) and torch.equal(a0["maxr"], one["maxr"])
