@@ -192,6 +192,15 @@ def _fill_params(net, grads=None):
     return P
 
 
+# Data-parallel hook: the gradient of the SH coefficients leaves the deformation field unchanged (shs_final =
+# shs + delta), so it is final before this module's backward kernels run.  When set, the callable receives that
+# tensor (a copy: the kernels still need the rank's own) right before the kernels are enqueued and may start an
+# in-place all-reduce on it; the handle it returns
+# (or None) is waited for (stream order only) after they are enqueued: 71 % of the gradient bytes then cross
+# the links beside the deformation backward instead of after it.
+RESIDUAL_GRAD_HOOK = None
+
+
 class _DeformFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, grad_mode, xyz, scales, rotations, opacity, shs, time, *params):
@@ -262,9 +271,15 @@ class _DeformFunction(torch.autograd.Function):
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
+        g_sh_out, pending = g_sh, None
+        if RESIDUAL_GRAD_HOOK is not None:
+            g_sh_out = g_sh.clone()          # the kernels below still read this rank's own cotangent
+            pending = RESIDUAL_GRAD_HOOK(g_sh_out)
         _lib.call("fdgs_deform_bwd", a)
+        if pending is not None:
+            pending.wait()
         # net, grad_mode, xyz, scales, rotations, opacity, shs, time, *params
-        return (None, None, d_xyz, g_sc, g_ro, g_op, g_sh, None) + tuple(grads)
+        return (None, None, d_xyz, g_sc, g_ro, g_op, g_sh_out, None) + tuple(grads)
 
 
 class DeformationFields(nn.Module):

@@ -34,6 +34,17 @@ def all_reduce_(t, op, group=None):
         dist.all_reduce(t, op=op, group=group)
 
 
+def all_reduce_async(t, op=None, group=None):
+    """Starts an in-place SUM all-reduce of `t` on the communication stream and returns a handle; its wait()
+    orders the current stream after the collective without blocking the host, so kernels enqueued between
+    the two calls run beside it.  Returns None when the reduction has already completed (gloo staging)."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        all_reduce_(t, op, group)
+        return None
+    return dist.all_reduce(t, op=op, group=group, async_op=True)
+
+
 @torch.no_grad()
 def broadcast_parameters(params, src=0, group=None):
     """Makes every rank's replica bit-identical to rank `src`'s (one flat broadcast)."""
@@ -115,9 +126,11 @@ def reduce_densification_stats(radii, visibility, viewspace_grad, group=None):
     if not is_dist():
         return radii, visibility, viewspace_grad
     r = radii.contiguous()
-    v = visibility.to(torch.uint8).contiguous()
     g = viewspace_grad.contiguous()
     all_reduce_(r, dist.ReduceOp.MAX, group)
-    all_reduce_(v, dist.ReduceOp.MAX, group)
+    if visibility is not None:          # None: the caller derives it as radii > 0, which commutes with the MAX
+        v = visibility.to(torch.uint8).contiguous()
+        all_reduce_(v, dist.ReduceOp.MAX, group)
+        visibility = v.bool()
     all_reduce_(g, dist.ReduceOp.SUM, group)
-    return r, v.bool(), g
+    return r, visibility, g

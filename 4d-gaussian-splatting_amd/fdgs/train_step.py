@@ -46,6 +46,9 @@ class TrainStep:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self.params = [p for grp in groups for p in grp["params"]]
         self.bucket = dp.GradBucket(self.params)
+        # the SH gradients can be exchanged early (fdgs.deformation.RESIDUAL_GRAD_HOOK); the rest then goes here
+        sh_ids = {id(gaussians._features_dc), id(gaussians._features_rest)}
+        self.bucket_without_sh = dp.GradBucket([p for p in self.params if id(p) not in sh_ids])
         dp.broadcast_parameters(self.params)      # replicas start identical whatever the ranks' RNG state was
         n = gaussians._xyz.shape[0]
         dev = gaussians._xyz.device
@@ -89,8 +92,20 @@ class TrainStep:
             reg_w = tuple(w * share for w in self.regulation)
             if not self.fused_tail and loss is not None:
                 loss = loss + losses.compute_regulation(self.deforms.deformation_fields, *reg_w)
+        early = []
         if loss is not None:
-            loss.backward()
+            from . import deformation
+            # one view on every rank (so all ranks take this branch together): the view's SH gradient is the
+            # rank's whole contribution and can be exchanged while the deformation backward runs
+            if dp.is_dist() and len(global_views) == dp.rank_world()[1]:
+                def hook(g_sh):
+                    early.append(g_sh)
+                    return dp.all_reduce_async(g_sh)
+                deformation.RESIDUAL_GRAD_HOOK = hook
+            try:
+                loss.backward()
+            finally:
+                deformation.RESIDUAL_GRAD_HOOK = None
         if reg_w is not None and self.fused_tail:
             # same gradients as adding the term to the loss, written into the planes' .grad in one launch
             reg = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
@@ -109,8 +124,11 @@ class TrainStep:
             vis = torch.zeros(n, dtype=torch.bool, device=dev)
             vgrad = torch.zeros(n, 3, device=dev)
         if dp.is_dist():
-            self.bucket.allreduce_()
-            radii, vis, vgrad = dp.reduce_densification_stats(radii, vis, vgrad)
+            # `early` is the same on every rank: the hook is armed only for one view per rank, and it fires
+            # once per fine-stage render
+            (self.bucket_without_sh if len(early) == 1 else self.bucket).allreduce_()
+            radii, _, vgrad = dp.reduce_densification_stats(radii, None, vgrad)
+            vis = radii > 0
         if self.fused_tail:     # fdgs_trainer.py:181-182, gaussian_model.py:182-184 in one launch
             losses.add_densification_stats(radii, vgrad, self.xyz_gradient_accum, self.denom, self.max_radii2D)
         else:
