@@ -190,7 +190,7 @@ plane_reg_final_kernel(const float* __restrict__ partial, int n, float* __restri
     if (threadIdx.x == 0) out[0] = (float)shd[0];
 }
 
-#define REG_BLOCKS_PER_PLANE 64
+#define REG_BLOCKS_PER_PLANE 256
 
 extern "C" size_t fdgs_plane_reg_partials(int32_t num_planes) {
     return (size_t)(num_planes > 0 ? num_planes : 1) * REG_BLOCKS_PER_PLANE;

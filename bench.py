@@ -273,6 +273,20 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dur * 1e3},
         }
+        # the HBM-bound stages beside the north-star kernel: algorithmic bytes per call over the call's time
+        # (N Gaussians, V visible, P parameters; the figures are those of the kernel table in DESIGN.md)
+        N, V = float(args.gaussians), float(visible)
+        n_param = float(sum(p.numel() for p in step.params))
+        def hbm(name, nbytes):
+            t = avg_ms(name) * 1e-3
+            return {"call": name, "bound": "hbm", "achieved": nbytes / t / 1e9 if t > 0 else 0.0, "peak": 8000.0,
+                    "unit": "GB/s", "frac": (nbytes / t / 1e9 / 8000.0) if t > 0 else 0.0}
+        out["roofline_hbm_calls"] = [
+            hbm("fdgs_raster_preprocess_bwd", 40.0 * V + 236.0 * N + 248.0 * N),
+            hbm("fdgs_adam_step", 28.0 * n_param),
+            hbm("fdgs_l1_loss_bwd", 12.0 * 3 * px),
+            hbm("fdgs_raster_blend_fwd", 44.0 * R + 28.0 * px),
+        ]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g, net, train_cams[0], bg)
         print(json.dumps(out), flush=True)
