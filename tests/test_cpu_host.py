@@ -101,3 +101,40 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text, f"{f} mentions the oracle"
+
+
+def test_scene_files_round_trip(tmp_path):
+    """fdgs.io: point_cloud.ply in the reference's layout (src/model/gaussian_model.py:101-171) and the
+    deformation checkpoint files (src/model/deformation_wrapper.py:31-47)."""
+    from fdgs import io as fio
+    from fdgs import scene_synth as ss
+    from fdgs.deformation import DeformationFields
+    g = ss.GaussianParams(257, device="cpu")
+    path = str(tmp_path / "iteration_7" / "point_cloud.ply")
+    fio.save_ply(path, g._xyz, g._features_dc, g._features_rest, g._opacity, g._scaling, g._rotation)
+    raw = open(path, "rb").read()
+    head, payload = raw.split(b"end_header\n", 1)
+    lines = head.decode().split("\n")
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 257"]
+    assert [l.split()[-1] for l in lines[3:-1]] == fio.ply_attributes() and len(fio.ply_attributes()) == 62
+    # payload as the reference assembles it: rows of (xyz, normals, f_dc^T, f_rest^T, opacity, scale, rotation)
+    rows = np.concatenate((g._xyz.detach().numpy(), np.zeros((257, 3), np.float32),
+                           g._features_dc.detach().transpose(1, 2).flatten(start_dim=1).numpy(),
+                           g._features_rest.detach().transpose(1, 2).flatten(start_dim=1).numpy(),
+                           g._opacity.detach().numpy(), g._scaling.detach().numpy(), g._rotation.detach().numpy()), axis=1)
+    assert payload == rows.astype("<f4").tobytes()
+    back = fio.load_ply(path)
+    for name, ref in (("xyz", g._xyz), ("features_dc", g._features_dc), ("features_rest", g._features_rest),
+                      ("opacity", g._opacity), ("scaling", g._scaling), ("rotation", g._rotation)):
+        assert back[name].shape == ref.shape and torch.equal(back[name], ref.detach()), name
+    with pytest.raises(ValueError):
+        fio.load_ply(path, max_sh_degree=2)
+
+    net = ss.perturb_deformation_(DeformationFields(ss.DYNERF_NET_KWARGS))
+    table = torch.rand(257) > 0.5
+    fio.save_deformation(str(tmp_path / "ckpt"), net, deformation_table=table)
+    net2 = DeformationFields(ss.DYNERF_NET_KWARGS)
+    t2, acc2 = fio.load_deformation(str(tmp_path / "ckpt"), net2, 257)
+    assert torch.equal(t2, table) and acc2.shape == (257, 3) and float(acc2.abs().sum()) == 0.0
+    for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert torch.equal(a, b), k
