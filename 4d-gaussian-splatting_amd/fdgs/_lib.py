@@ -157,11 +157,12 @@ SYMBOLS = {
     "fdgs_densify_stats": (C.c_int, [C.POINTER(DensifyStatsArgs), c_p]),
     "fdgs_plane_reg_partials": (c_sz, [c_i32]),
     "fdgs_plane_regulation": (C.c_int, [C.POINTER(PlaneRegArgs), c_p]),
+    "fdgs_knn_mean_dist2": (C.c_int, [c_p, c_i32, c_p, c_p]),
     "fdgs_adam_step": (C.c_int, [C.POINTER(AdamArgs), c_p]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def _load():

@@ -341,6 +341,11 @@ typedef struct {
 size_t fdgs_plane_reg_partials(int32_t num_planes);
 int fdgs_plane_regulation(const fdgs_plane_reg_args* a, void* stream);
 
+/* ---- initial scales: mean squared distance to the three nearest other points, `simple_knn._C.distCUDA2` at
+ * src/model/gaussian_model.py:57 (with fewer than four points the missing neighbours count as +inf, as there).
+ * points [N,3] -> mean_dist2 [N]. */
+int fdgs_knn_mean_dist2(const float* points, int32_t num_points, float* mean_dist2, void* stream);
+
 /* ---- Adam ------------------------------------------------------------------------------------
  * One step of torch.optim.Adam (no weight decay, no amsgrad) over up to 48 tensors in one launch:
  * the optimizer the reference builds at src/runner/fdgs_trainer.py:262-274 (eps 1e-15, one learning

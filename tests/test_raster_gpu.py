@@ -258,3 +258,19 @@ def test_l1_loss_and_densification_stats_match_torch():
     losses.add_densification_stats(radii, vgrad, acc, den, mx)
     assert torch.equal(mx, mx_r) and torch.equal(den, den_r)
     assert float((acc - acc_r).abs().max()) <= 1e-6
+
+
+def test_distCUDA2_matches_all_pairs_search():
+    """simple_knn._C.distCUDA2 (src/model/gaussian_model.py:57) against an all-pairs top-3 in float64; with
+    duplicate points (distance 0 counts, the point itself does not) and a size that is no multiple of the tile."""
+    from simple_knn._C import distCUDA2
+    gen = torch.Generator().manual_seed(21)
+    pts = torch.randn(3001, 3, generator=gen)
+    pts[100] = pts[7]; pts[101] = pts[7]                  # a triple
+    got = distCUDA2(pts.cuda()).cpu()
+    d = torch.cdist(pts.double(), pts.double()) ** 2
+    d.fill_diagonal_(float("inf"))
+    ref = d.topk(3, dim=1, largest=False).values.mean(dim=1)
+    assert got.shape == (3001,)
+    assert float((got.double() - ref).abs().max() / ref.max()) <= 1e-6
+    assert float(got[7]) <= 1e-6 * float(ref.max()) + float(ref[7]) * 1.001 and float(ref[7]) > 0   # two zeros + one real
