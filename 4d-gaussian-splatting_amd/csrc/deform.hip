@@ -1098,6 +1098,16 @@ static int bwd_chunk_points(int n) {
 static size_t bwd_ysplit_floats(int matmul, int n) {
     return matmul == FDGS_MATMUL_SPLIT_BF16 ? (size_t)192 * (bwd_chunk_points(n) + 16) : 0;
 }
+// plane features pre-split as the B operand of the dW0 product (one column block, 192 bytes per point)
+#define DW0_SLABS 16
+#define W2_SLABS 16
+#define W2_SLAB_FLOATS (59 * DW + 5 * 64)                 // the five dW2 (59 rows) and db2 (5 x 64, padded)
+// + DW0_SLABS private copies of dW0 (128 x 32) and db0 (128), + W2_SLABS copies of dW2 / db2
+static size_t bwd_yfeat_floats(int matmul, int n) {
+    return matmul == FDGS_MATMUL_SPLIT_BF16
+               ? (size_t)48 * ((size_t)n + 16) + (size_t)DW0_SLABS * (DW * 32 + DW) + (size_t)W2_SLABS * W2_SLAB_FLOATS
+               : 0;
+}
 // brick binning of the HexPlane backward, in 4-byte words: perm [n], brick_of [n] (16 bit, rounded up),
 // counts / cursor [BRICK_MAX] each, work count (16 words), work items [3 x max_work]
 static int brick_max_work(int n) { return BRICK_MAX + n / BRICK_CH + 1; }
@@ -1111,7 +1121,7 @@ extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, i
     const size_t per_point = DW + 32 + 32;
     return (2 * pf + bwd_packed_floats(p->matmul) + per_point * (size_t)num_points +
             (size_t)1280 * bwd_chunk_points(num_points) + bwd_ysplit_floats(p->matmul, num_points) +
-            bwd_brick_words(num_points)) * sizeof(float);
+            bwd_yfeat_floats(p->matmul, num_points) + bwd_brick_words(num_points)) * sizeof(float);
 }
 
 // The HexPlane scatter (atomics-bound) and the weight-gradient products (matrix-core / memory-bound) only
@@ -1158,7 +1168,8 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
 
     float* ws_df = ws_feat + (size_t)32 * n;
     float* ws_ysplit = ws_df + (size_t)32 * n;      // split mode only (sized by fdgs_deform_bwd_workspace_bytes)
-    int* ws_brick = reinterpret_cast<int*>(ws_ysplit + bwd_ysplit_floats(a->p.matmul, n));
+    float* ws_yfeat = ws_ysplit + bwd_ysplit_floats(a->p.matmul, n);
+    int* ws_brick = reinterpret_cast<int*>(ws_yfeat + bwd_yfeat_floats(a->p.matmul, n));
 
     HexBwdK hk;
     hk.n = n;
@@ -1300,7 +1311,42 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             hipLaunchKernelGGL(hexplane_bwd_kernel, dim3((unsigned)hb), dim3(256), hex_lds_bytes, hs, hk, hex_lds_floats);
             FDGS_CHECK_LAUNCH();
         }
-        {                                           // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f]
+        if (a->p.matmul == FDGS_MATMUL_SPLIT_BF16) {
+            // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f], db0 = column sums of dhid: the same split product as
+            // the dW1 kernels, with one 32-column block (features pre-split in points-as-K order first)
+            const int chunks = (n + 15) / 16;
+            WGradPrepK pk;
+            pk.n = n;
+            pk.d[0] = WGradPrepDesc{ws_feat, 32, 32, 1, 0, reinterpret_cast<u32x4*>(ws_yfeat), nullptr};
+            for (int i = 1; i < WPREP_MAX; ++i) pk.d[i] = pk.d[0];
+            int pblocks = (chunks + 3) / 4;
+            if (pblocks > 4096) pblocks = 4096;
+            hipLaunchKernelGGL(wgrad_prep_split_kernel, dim3(pblocks, 1), dim3(256), 0, hs, pk);
+            FDGS_CHECK_LAUNCH();
+            int per = (chunks + 1023) / 1024;
+            if (per < 4) per = 4;
+            WGradSK w1;
+            w1.n = n;
+            w1.chunks_per_block = per;
+            for (int i = 0; i < WGS_MAX; ++i) w1.d[i].C = nullptr;
+            // dW0 is 128 rows of 128 bytes: every workgroup would hit every one of them; private copies instead
+            float* slab_w = ws_yfeat + (size_t)48 * ((size_t)n + 16);
+            float* slab_b = slab_w + (size_t)DW0_SLABS * DW * 32;
+            if (hipMemsetAsync(slab_w, 0, (size_t)DW0_SLABS * (DW * 32 + DW) * sizeof(float), hs) != hipSuccess)
+                return FDGS_ELAUNCH;
+            w1.d[0] = WGradSDesc{ws_dhid, DW, reinterpret_cast<const u32x4*>(ws_yfeat), slab_w, 32, 1, 32,
+                                 a->dp.b0 ? slab_b : nullptr, DW0_SLABS, DW * 32, DW};
+            if (!a->dp.w0) w1.d[0].C = nullptr;
+            hipLaunchKernelGGL(deform_wgrad_split_kernel<1>, dim3((chunks + per - 1) / per, 1), dim3(256), 0, hs, w1);
+            FDGS_CHECK_LAUNCH();
+            SlabReduceK sr;
+            for (int e = 0; e < SLAB_ENTRIES; ++e) { sr.slab[e] = nullptr; sr.out[e] = nullptr; sr.count[e] = 0; sr.stride[e] = 0; }
+            sr.slab[0] = slab_w; sr.out[0] = a->dp.w0; sr.count[0] = DW * 32; sr.stride[0] = DW * 32;
+            sr.slab[1] = slab_b; sr.out[1] = a->dp.w0 ? a->dp.b0 : nullptr; sr.count[1] = DW; sr.stride[1] = DW;
+            sr.slabs = DW0_SLABS;
+            hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(DW * 32 / 256, 2), dim3(256), 0, hs, sr);
+            FDGS_CHECK_LAUNCH();
+        } else {                                    // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f]  (fp32 MFMA)
             WGradK w;
             w.n = n;
             w.chunk = 1024;
@@ -1339,6 +1385,10 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     static const int kdim[5] = {3, 3, 4, 1, 48};
     const float* gs[5] = {a->g_xyz, a->g_scales, a->g_rotations, a->g_opacity, a->g_shs};
     const int chunk_pts = bwd_chunk_points(n);
+    // private copies of the small dW2 / db2 accumulators (split mode), folded into the outputs after the loop
+    float* w2_slabs = ws_yfeat + (size_t)48 * ((size_t)n + 16) + (size_t)DW0_SLABS * (DW * 32 + DW);
+    if (split && hipMemsetAsync(w2_slabs, 0, (size_t)W2_SLABS * W2_SLAB_FLOATS * sizeof(float), s) != hipSuccess)
+        return FDGS_ELAUNCH;
     for (int c0 = 0; c0 < n; c0 += chunk_pts) {
         const int cn = (n - c0) < chunk_pts ? (n - c0) : chunk_pts;
         DeformBwdK kc = k;
@@ -1388,7 +1438,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             w4.chunks_per_block = per;
             for (int i = 0; i < WGS_MAX; ++i) w4.d[i].C = nullptr;
             for (int h = 0; h < 5; ++h)
-                w4.d[h] = WGradSDesc{ws_dh1 + (size_t)h * chunk_cap * DW, DW, y_hidden, a->dp.w1[h], DW, 1, DW, a->dp.b1[h]};
+                w4.d[h] = WGradSDesc{ws_dh1 + (size_t)h * chunk_cap * DW, DW, y_hidden, a->dp.w1[h], DW, 1, DW, a->dp.b1[h], 0, 0, 0};
             hipLaunchKernelGGL(deform_wgrad_split_kernel<4>, dim3((chunks + per - 1) / per, 5), dim3(256), 0, s, w4);
             FDGS_CHECK_LAUNCH();
             // dW2_h = g_h^T relu(h1_h) with h1 recomputed in place (nothing stored), db2_h = column sums of g_h
@@ -1406,6 +1456,8 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                 cs.X[h] = kc.g[h]; cs.ncols[h] = kdim[h]; cs.out[h] = a->dp.b2[h];
             }
             w2k.tiles_per_block = tpb = (tiles + 1023) / 1024;       // about 1000 waves per launch
+            w2k.dw2_slabs = w2_slabs; w2k.slabs = W2_SLABS;
+            cs.slabs_base = w2_slabs + (size_t)W2_SLABS * 59 * DW; cs.slabs = W2_SLABS;
             hipLaunchKernelGGL(deform_wgrad2_split_kernel<1>, dim3((tiles + tpb - 1) / tpb), dim3(64), 0, s, w2k);
             FDGS_CHECK_LAUNCH();
             hipLaunchKernelGGL(deform_wgrad2_split_kernel<2>, dim3((tiles + tpb - 1) / tpb), dim3(64), 0, s, w2k);
@@ -1435,6 +1487,20 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             w.d[i].M = 0; w.d[i].NN = 0; w.d[i].ldx = w.d[i].ldy = w.d[i].ldc = 0; w.d[i].relu_y = 0;
         }
         hipLaunchKernelGGL(deform_wgrad_kernel, dim3((cn + w.chunk - 1) / w.chunk, nd), dim3(256), 0, s, w);
+        FDGS_CHECK_LAUNCH();
+    }
+    if (split) {
+        static const int row0[5] = {0, 3, 6, 10, 11};
+        SlabReduceK sr;
+        for (int e = 0; e < SLAB_ENTRIES; ++e) { sr.slab[e] = nullptr; sr.out[e] = nullptr; sr.count[e] = 0; sr.stride[e] = 0; }
+        for (int h = 0; h < 5; ++h) {
+            sr.slab[h] = w2_slabs + (size_t)row0[h] * DW; sr.out[h] = a->dp.w2[h];
+            sr.count[h] = kdim[h] * DW; sr.stride[h] = 59 * DW;
+            sr.slab[5 + h] = w2_slabs + (size_t)W2_SLABS * 59 * DW + 64 * h; sr.out[5 + h] = a->dp.b2[h];
+            sr.count[5 + h] = kdim[h]; sr.stride[5 + h] = 5 * 64;
+        }
+        sr.slabs = W2_SLABS;
+        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(8, 10), dim3(256), 0, s, sr);
         FDGS_CHECK_LAUNCH();
     }
     if (side) {                                 // join

@@ -817,6 +817,10 @@ struct WGradSDesc {
     const u32x4* ysplit;
     float* C; int sm; int sn; int nvalid;
     float* rowsum;
+    // a small C (few cache lines) would take one atomic per line from every workgroup, and atomics to one line
+    // serialise in its L2 channel: workgroup b then adds into copy b % slabs at C + (b % slabs) * slab_stride
+    // (rowsum follows at its own stride) and wgrad_slab_reduce_kernel folds the copies; slabs <= 1: no copies
+    int slabs; int slab_stride; int rowsum_slab_stride;
 };
 #define WGS_MAX 6
 struct WGradSK {
@@ -908,16 +912,37 @@ deform_wgrad_split_kernel(WGradSK a) {
             }
         }
     }
+    const int slab = d.slabs > 1 ? (int)(blockIdx.x % (unsigned)d.slabs) : 0;
+    float* __restrict__ Cs = d.C + (size_t)slab * d.slab_stride;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
         const int n = 32 * nb + c;
         if (n < d.nvalid) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                atomicAdd(d.C + (size_t)(32 * mb + drow(r, g)) * d.sm + (size_t)n * d.sn, acc[nb][r]);
+                atomicAdd(Cs + (size_t)(32 * mb + drow(r, g)) * d.sm + (size_t)n * d.sn, acc[nb][r]);
         }
     }
-    if (d.rowsum) atomicAdd(d.rowsum + 32 * mb + c, bsum);
+    if (d.rowsum) atomicAdd(d.rowsum + (size_t)slab * d.rowsum_slab_stride + 32 * mb + c, bsum);
+}
+
+// out[e][i] += sum over the copies of slab[e][s * stride[e] + i]  (i < count[e]) for up to SLAB_ENTRIES destinations
+#define SLAB_ENTRIES 12
+struct SlabReduceK { const float* slab[SLAB_ENTRIES]; float* out[SLAB_ENTRIES]; int count[SLAB_ENTRIES];
+                     int stride[SLAB_ENTRIES]; int slabs; };
+__global__ void __launch_bounds__(256)
+wgrad_slab_reduce_kernel(SlabReduceK a) {
+    const float* __restrict__ src = a.slab[0]; float* __restrict__ dst = a.out[0];
+    int count = a.count[0], stride = a.stride[0];
+#pragma unroll
+    for (int e = 1; e < SLAB_ENTRIES; ++e)
+        if ((int)blockIdx.y == e) { src = a.slab[e]; dst = a.out[e]; count = a.count[e]; stride = a.stride[e]; }
+    if (!dst) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+        float s = 0.0f;
+        for (int k = 0; k < a.slabs; ++k) s += src[(size_t)k * stride + i];
+        dst[i] += s;
+    }
 }
 
 
@@ -939,6 +964,10 @@ struct WGrad2SK {
     const float* b1[5];
     const float* g[5];                           // cotangents [n,k]
     float* dw2[5];                               // [k,128]
+    // private copies of the 59 x 128 block of all five dW2 (rows 0-2 pos, 3-5 scales, 6-9 rotations, 10 opacity,
+    // 11-58 shs): wave b adds into copy b % slabs (every wave hits every line of its heads, and atomics to one
+    // line serialise in its L2 channel); wgrad_slab_reduce_kernel folds them into dw2.  NULL: straight into dw2
+    float* dw2_slabs; int slabs;
 };
 
 // NOB = 2: the shs head alone (48 rows = two row blocks).  NOB = 1: the four small heads TOGETHER, their
@@ -1051,12 +1080,21 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
                     o = row - (head == 0 ? 0 : head == 1 ? 3 : head == 2 ? 6 : 10);
                 }
                 float* dw2 = sel5(a.dw2, head);
-                if (row < (NOB == 1 ? 11 : 48) && dw2) atomicAdd(dw2 + (size_t)o * DW + 32 * fb + c, c2[ob][fb][r]);
+                if (row < (NOB == 1 ? 11 : 48) && dw2) {
+                    if (a.dw2_slabs) {
+                        float* dst = a.dw2_slabs + (size_t)(blockIdx.x % (unsigned)a.slabs) * (59 * DW) +
+                                     (size_t)((NOB == 1 ? 0 : 11) + row) * DW;
+                        atomicAdd(dst + 32 * fb + c, c2[ob][fb][r]);
+                    } else {
+                        atomicAdd(dw2 + (size_t)o * DW + 32 * fb + c, c2[ob][fb][r]);
+                    }
+                }
             }
 }
 
 // column sums of a small row-major matrix: out[j] += sum_p X[p][j], j < ncols <= 64 (the b2 gradients)
-struct ColSumK { const float* X[5]; int ncols[5]; float* out[5]; int n; };
+struct ColSumK { const float* X[5]; int ncols[5]; float* out[5]; int n;
+                 float* slabs_base; int slabs; };   // copies [slabs][5][64] instead of out (same reason as above)
 __global__ void __launch_bounds__(256)
 colsum_kernel(ColSumK a) {
     const int hd = blockIdx.y;
@@ -1081,5 +1119,8 @@ colsum_kernel(ColSumK a) {
         atomicAdd(&acc[tg % nc], (s0 + s1) + (s2 + s3));
     }
     __syncthreads();
-    if ((int)threadIdx.x < nc) atomicAdd(out + threadIdx.x, acc[threadIdx.x]);
+    if ((int)threadIdx.x < nc) {
+        float* dst = a.slabs_base ? a.slabs_base + ((size_t)(blockIdx.x % (unsigned)a.slabs) * 5 + hd) * 64 : out;
+        atomicAdd(dst + threadIdx.x, acc[threadIdx.x]);
+    }
 }
