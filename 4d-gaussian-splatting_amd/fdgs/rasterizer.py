@@ -88,29 +88,33 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
                                ptr(scan_ws), int(activations))
     _lib.call("fdgs_raster_preprocess_fwd", a)
 
+    # everything whose size is known is allocated while the preprocess kernels run, before the host waits
+    st.color = torch.empty(3, H, W, device=dev, dtype=torch.float32)
+    st.depth = torch.empty(1, H, W, device=dev, dtype=torch.float32)
+    st.final_T = torch.empty(H, W, device=dev, dtype=torch.float32)
+    st.n_contrib = torch.empty(H, W, device=dev, dtype=torch.int32)
+    st.ranges = torch.empty(gx * gy, 2, device=dev, dtype=torch.int32)
+    # ... the R-sized ones too, at the capacity of the previous calls (redone below in the rare case R outgrew it)
+    def list_buffers(cap):
+        ws_bytes = lib.fdgs_raster_sort_workspace_bytes(cap)
+        return (cap, torch.empty(cap, device=dev, dtype=torch.int64), torch.empty(cap, device=dev, dtype=torch.int32),
+                torch.empty(cap, device=dev, dtype=torch.int64), torch.empty(cap, device=dev, dtype=torch.int32),
+                torch.empty(ws_bytes, device=dev, dtype=torch.uint8), ws_bytes)
+    bufs = list_buffers(_LIST_CAPACITY) if _LIST_CAPACITY > 0 else None
     # the data-dependent list length R: one small device->host read (stream sync)
     R = int(st.point_offsets[-1].item()) if N > 0 else 0
     st.num_rendered = R
     global LAST_NUM_RENDERED
     LAST_NUM_RENDERED = R
-    cap = _list_capacity(max(R, 1))
-    keys_a = torch.empty(cap, device=dev, dtype=torch.int64)
-    vals_a = torch.empty(cap, device=dev, dtype=torch.int32)
-    st.keys_sorted = torch.empty(cap, device=dev, dtype=torch.int64)
-    st.vals_sorted = torch.empty(cap, device=dev, dtype=torch.int32)
-    st.ranges = torch.empty(gx * gy, 2, device=dev, dtype=torch.int32)
-    ws_bytes = max(lib.fdgs_raster_sort_workspace_bytes(cap), lib.fdgs_raster_sort_workspace_bytes(R))
-    sort_ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    if bufs is None or R > bufs[0]:
+        bufs = list_buffers(_list_capacity(max(R, 1)))
+    _, keys_a, vals_a, st.keys_sorted, st.vals_sorted, sort_ws, ws_bytes = bufs
     b = _lib.BinSortArgs(N, W, H, R, ptr(st.geom), ptr(st.point_offsets), ptr(keys_a), ptr(vals_a),
                          ptr(st.keys_sorted), ptr(st.vals_sorted), ptr(st.ranges), ptr(sort_ws), ws_bytes)
     _lib.call("fdgs_raster_bin_sort", b)
     if not keep_keys:
         st.keys_sorted = None
 
-    st.color = torch.empty(3, H, W, device=dev, dtype=torch.float32)
-    st.depth = torch.empty(1, H, W, device=dev, dtype=torch.float32)
-    st.final_T = torch.empty(H, W, device=dev, dtype=torch.float32)
-    st.n_contrib = torch.empty(H, W, device=dev, dtype=torch.int32)
     c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted), ptr(st.geom), ptr(bg), ptr(st.color),
                           ptr(st.depth), ptr(st.final_T), ptr(st.n_contrib))
     _lib.call("fdgs_raster_blend_fwd", c)
