@@ -1,6 +1,7 @@
 // Stage 4: stable LSD radix sort of (uint64 key, uint32 value) pairs for gfx950.
 //
-// 8-bit digits.  Per pass three launches:
+// 9-bit digits (the 45 key bits of a 1352 x 1014 frame - 13 tile bits + 32 depth bits - take five passes instead
+// of the six that 8-bit digits need).  Per pass three launches:
 //   1. digit histogram per block (LDS atomics), stored digit-major  hist[d][block]
 //   2. one block per digit: exclusive scan of its row + the digit total
 //   3. scatter: each block walks its range in sub-tiles of 2048 keys; ranks are
@@ -16,7 +17,8 @@
 #define RS_IPL 8                                    // items per lane
 #define RS_SUBTILE (RS_THREADS * RS_IPL)            // 2048 keys
 #define RS_MAX_BLOCKS 1024
-#define RS_BINS 256
+#define RS_BITS 9
+#define RS_BINS (1 << RS_BITS)                       // 512: two digits per thread where a thread owns digits
 
 struct rs_plan {
     int blocks;
@@ -44,7 +46,7 @@ __global__ void __launch_bounds__(RS_THREADS)
 rs_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int64_t per_block, int shift, uint32_t mask,
                uint32_t* __restrict__ hist, int nblocks) {
     __shared__ uint32_t h[RS_BINS];
-    h[threadIdx.x] = 0;
+    for (int d = threadIdx.x; d < RS_BINS; d += RS_THREADS) h[d] = 0;
     __syncthreads();
     const int64_t begin = (int64_t)blockIdx.x * per_block;
     int64_t end = begin + per_block;
@@ -54,7 +56,7 @@ rs_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int64_t per_block, 
         atomicAdd(&h[d], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (int d = threadIdx.x; d < RS_BINS; d += RS_THREADS) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
 }
 
 // One block per digit: exclusive scan of hist[d][0..nblocks) in place, total[d].
@@ -103,9 +105,11 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
     __shared__ uint32_t wsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    // digit base = exclusive scan of the 256 totals, + this block's prefix inside the digit row
+    // digit base = exclusive scan of the RS_BINS totals (thread t owns digits 2t and 2t+1), + this block's prefix
+    // inside the digit row
     {
-        const uint32_t t = totals[threadIdx.x];
+        const uint32_t t0 = totals[2 * threadIdx.x], t1 = totals[2 * threadIdx.x + 1];
+        const uint32_t t = t0 + t1;
         uint32_t incl = t;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -118,7 +122,9 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
 #pragma unroll
         for (int w = 0; w < 4; ++w)
             if (w < wave) base += wsum[w];
-        running[threadIdx.x] = base + incl - t + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+        const uint32_t excl = base + incl - t;
+        running[2 * threadIdx.x] = excl + hist[(size_t)(2 * threadIdx.x) * nblocks + blockIdx.x];
+        running[2 * threadIdx.x + 1] = excl + t0 + hist[(size_t)(2 * threadIdx.x + 1) * nblocks + blockIdx.x];
     }
 
     const int64_t begin = (int64_t)blockIdx.x * per_block;
@@ -128,7 +134,8 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
 
     for (int64_t tile = begin; tile < end; tile += RS_SUBTILE) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) wave_cnt[w][threadIdx.x] = 0;
+        for (int w = 0; w < 4; ++w)
+            for (int d = threadIdx.x; d < RS_BINS; d += RS_THREADS) wave_cnt[w][d] = 0;
         __syncthreads();
 
         uint64_t key[RS_IPL];
@@ -150,7 +157,7 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
             // lanes of this wave holding the same digit (invalid lanes match nobody valid)
             unsigned long long peers = __ballot(ok);
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
+            for (int b = 0; b < RS_BITS; ++b) {
                 const unsigned long long bal = __ballot((d >> b) & 1u);
                 peers &= ((d >> b) & 1u) ? bal : ~bal;
             }
@@ -161,8 +168,8 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
             if (ok && before == 0) wave_cnt[wave][d] = prev + (uint32_t)__popcll(peers);
         }
         __syncthreads();
-        {   // per digit: turn the four wave counts into wave bases, advance the running slot
-            const int d = threadIdx.x;
+        // per digit: turn the four wave counts into wave bases, advance the running slot
+        for (int d = threadIdx.x; d < RS_BINS; d += RS_THREADS) {
             uint32_t c0 = wave_cnt[0][d], c1 = wave_cnt[1][d], c2 = wave_cnt[2][d], c3 = wave_cnt[3][d];
             const uint32_t g = running[d];
             wave_cnt[0][d] = g;
@@ -186,8 +193,8 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
     }
 }
 
-// Number of 8-bit passes needed for bits [0,end_bit).
-int fdgs_radix_sort_passes(int end_bit) { return (end_bit + 7) / 8; }
+// Number of RS_BITS-bit passes needed for bits [0,end_bit).
+int fdgs_radix_sort_passes(int end_bit) { return (end_bit + RS_BITS - 1) / RS_BITS; }
 
 // Sorts n pairs.  Pass p reads buffer (p even ? A : B) and writes the other one,
 // where A = (keys_a, vals_a).  The result is in B after an odd number of passes
@@ -201,8 +208,8 @@ int fdgs_radix_sort_pingpong(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_
     const rs_plan plan = rs_make_plan(n);
     const int passes = fdgs_radix_sort_passes(end_bit);
     for (int p = 0; p < passes; ++p) {
-        const int shift = 8 * p;
-        const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        const int shift = RS_BITS * p;
+        const int bits = (end_bit - shift) < RS_BITS ? (end_bit - shift) : RS_BITS;
         const uint32_t mask = (1u << bits) - 1u;
         const uint64_t* kin = (p & 1) ? keys_b : keys_a;
         const uint32_t* vin = (p & 1) ? vals_b : vals_a;
