@@ -4,6 +4,8 @@ batch, backward, view-space gradient / radii / visibility statistics, Adam step
 with the reference's eight parameter groups (:262-274, eps 1e-15).  With
 torch.distributed initialised the views are sharded over ranks and gradients
 and statistics are all-reduced (fdgs.dp)."""
+import os
+
 import torch
 
 from . import dp, losses
@@ -49,6 +51,7 @@ class TrainStep:
         # the SH gradients can be exchanged early (fdgs.deformation.RESIDUAL_GRAD_HOOK); the rest then goes here
         sh_ids = {id(gaussians._features_dc), id(gaussians._features_rest)}
         self.bucket_without_sh = dp.GradBucket([p for p in self.params if id(p) not in sh_ids])
+        self.early_exchange = os.environ.get("FDGS_DP_EARLY", "1") != "0"
         dp.broadcast_parameters(self.params)      # replicas start identical whatever the ranks' RNG state was
         n = gaussians._xyz.shape[0]
         dev = gaussians._xyz.device
@@ -97,10 +100,15 @@ class TrainStep:
             from . import deformation
             # one view on every rank (so all ranks take this branch together): the view's SH gradient is the
             # rank's whole contribution and can be exchanged while the deformation backward runs
-            if dp.is_dist() and len(global_views) == dp.rank_world()[1]:
+            if dp.is_dist() and len(global_views) == dp.rank_world()[1] and self.early_exchange:
                 def hook(g_sh):
+                    try:
+                        work = dp.all_reduce_async(g_sh)
+                    except Exception:       # the collective could not be started (the same on every rank): the
+                        self.early_exchange = False     # gradient then travels with the bucket, now and later
+                        return None
                     early.append(g_sh)
-                    return dp.all_reduce_async(g_sh)
+                    return work
                 deformation.RESIDUAL_GRAD_HOOK = hook
             try:
                 loss.backward()
