@@ -22,6 +22,7 @@
 #include "fdgs_common.h"
 #include <mutex>
 #include <cstdlib>
+#include <type_traits>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -1335,7 +1336,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             if (hipMemsetAsync(slab_w, 0, (size_t)DW0_SLABS * (DW * 32 + DW) * sizeof(float), hs) != hipSuccess)
                 return FDGS_ELAUNCH;
             w1.d[0] = WGradSDesc{ws_dhid, DW, reinterpret_cast<const u32x4*>(ws_yfeat), slab_w, 32, 1, 32,
-                                 a->dp.b0 ? slab_b : nullptr, DW0_SLABS, DW * 32, DW};
+                                 a->dp.b0 ? slab_b : nullptr, DW0_SLABS, DW * 32, DW, nullptr, 0, nullptr, nullptr};
             if (!a->dp.w0) w1.d[0].C = nullptr;
             hipLaunchKernelGGL(deform_wgrad_split_kernel<1>, dim3((chunks + per - 1) / per, 1), dim3(256), 0, hs, w1);
             FDGS_CHECK_LAUNCH();
@@ -1438,7 +1439,15 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             w4.chunks_per_block = per;
             for (int i = 0; i < WGS_MAX; ++i) w4.d[i].C = nullptr;
             for (int h = 0; h < 5; ++h)
-                w4.d[h] = WGradSDesc{ws_dh1 + (size_t)h * chunk_cap * DW, DW, y_hidden, a->dp.w1[h], DW, 1, DW, a->dp.b1[h], 0, 0, 0};
+                {
+                    w4.d[h] = WGradSDesc{ws_dh1 + (size_t)h * chunk_cap * DW, DW, y_hidden, a->dp.w1[h], DW, 1, DW,
+                                         a->dp.b1[h], 0, 0, 0, nullptr, 0, nullptr, nullptr};
+                    if (h < 4) {            // dh1 of the small heads is not stored: formed from g, W2 and the masks
+                        w4.d[h].X = nullptr;
+                        w4.d[h].cot = kc.g[h]; w4.d[h].k = kdim[h]; w4.d[h].w2 = a->p.w2[h];
+                        w4.d[h].mask = reinterpret_cast<const uint2*>(a->mask) + ((size_t)h * n + c0) * 2;
+                    }
+                }
             hipLaunchKernelGGL(deform_wgrad_split_kernel<4>, dim3((chunks + per - 1) / per, 5), dim3(256), 0, s, w4);
             FDGS_CHECK_LAUNCH();
             // dW2_h = g_h^T relu(h1_h) with h1 recomputed in place (nothing stored), db2_h = column sums of g_h

@@ -18,6 +18,7 @@
 //     kidx(j, g, e) = 16 j + 8 (e>>2) + 4 g + (e&3),   e = 0..7
 // and the weights are packed to that order (three 1-KiB pieces per fragment).
 #pragma once
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -715,7 +716,7 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
             for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    if (pvalid[cb])
+                    if (pvalid[cb] && head == 4)     // the small heads' dh1 is re-formed inside the dW1 product
                         *reinterpret_cast<float4*>(a.ws_dh1 + ((size_t)head * a.dh1_rows + p[cb]) * DW + 32 * nb + 8 * q + 4 * h) =
                             make_float4(t[cb][nb][4 * q], t[cb][nb][4 * q + 1], t[cb][nb][4 * q + 2], t[cb][nb][4 * q + 3]);
         }
@@ -821,6 +822,10 @@ struct WGradSDesc {
     // serialise in its L2 channel: workgroup b then adds into copy b % slabs at C + (b % slabs) * slab_stride
     // (rowsum follows at its own stride) and wgrad_slab_reduce_kernel folds the copies; slabs <= 1: no copies
     int slabs; int slab_stride; int rowsum_slab_stride;
+    // X not stored but formed here (the heads with k <= 4 outputs): X[p][m] = [h1[p][m] > 0] sum_o w2[o][m] cot[p][o],
+    // from the head's cotangent [n,k], its last-layer weights [k,128] and the forward's ReLU bit masks (layout of
+    // relu_mask_build, mask[p * 2 + half]).  cot == NULL: X is read from memory
+    const float* cot; int k; const float* w2; const uint2* mask;
 };
 #define WGS_MAX 6
 struct WGradSK {
@@ -855,6 +860,32 @@ deform_wgrad_split_kernel(WGradSK a) {
     // fetched per wave they make this kernel L2-bandwidth bound (12 KiB per 24 MFMAs).
     constexpr int XA = 4;
     __shared__ u32x4 ybuf[2][4 * 3 * 64];
+    // on-the-fly X: per wave, the 16 x k cotangents and the 32 mask words of a chunk pass through LDS so that
+    // every lane can read those of its eight points (broadcast reads)
+    __shared__ float fly_cot[4][64];
+    __shared__ unsigned fly_msk[4][32];
+    const bool fly = d.cot != nullptr;
+    float cotr[XA];
+    unsigned mskr[XA];
+    float w2v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (fly) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < d.k) w2v[o] = d.w2[o * DW + 32 * mb + c];
+    }
+    // feature 32 mb + c sits in the mask of lane half (c >> 2) & 1, word mb >> 1, at bit 31 - (16 (mb & 1) + r)
+    // with r = (c & 3) + 4 ((c >> 3) & 3)
+    const int fly_half = (c >> 2) & 1;
+    const int fly_bit = 31 - (16 * (mb & 1) + (c & 3) + 4 * ((c >> 3) & 3));
+    auto load_fly = [&](int ch, float& co, unsigned& mo) {
+        const int pb = ch * 16;
+        co = 0.0f; mo = 0u;
+        if (lane < 16 * d.k && pb + lane / d.k < a.n) co = d.cot[(size_t)pb * d.k + lane];
+        if (lane < 32 && pb + (lane >> 1) < a.n) {
+            const uint2 m = d.mask[(size_t)pb * 2 + lane];
+            mo = (mb >> 1) ? m.y : m.x;
+        }
+    };
     float xr[XA][8];
     auto load_x = [&](int ch, float* xo) {
         const int pb = ch * 16;
@@ -871,7 +902,10 @@ deform_wgrad_split_kernel(WGradSK a) {
     };
 #pragma unroll
     for (int i = 0; i < XA; ++i)
-        if (ch_begin + i < ch_end) load_x(ch_begin + i, xr[i]);
+        if (ch_begin + i < ch_end) {
+            if (fly) load_fly(ch_begin + i, cotr[i], mskr[i]);
+            else load_x(ch_begin + i, xr[i]);
+        }
     Split3 ystage;                               // this wave's share (column block mb) of the next chunk
     if (mb < NB) {
         ystage = sfrag_load(d.ysplit, ch_begin, NB, mb, lane);
@@ -880,7 +914,50 @@ deform_wgrad_split_kernel(WGradSK a) {
         ybuf[0][(mb * 3 + 2) * 64 + lane] = ystage.l;
     }
     __syncthreads();
+    // X of chunk `ch` as split operand pieces, from ring stage i (static); refills the stage for chunk ch + XA.
+    // It is called for the NEXT chunk right after the current chunk's MFMAs are issued, so that its vector and
+    // LDS work runs under the matrix pipeline.
+    auto fly_point = [&](auto kc, int pt) -> float {       // kc: the head's output count as a compile-time value
+        constexpr int K = decltype(kc)::value;
+        float cv[K];
+#pragma unroll
+        for (int o = 0; o < K; ++o) cv[o] = fly_cot[mb][pt * K + o];
+        float x = 0.0f;
+#pragma unroll
+        for (int o = 0; o < K; ++o) x = fmaf(w2v[o], cv[o], x);
+        const int masked = __builtin_amdgcn_sbfe((int)fly_msk[mb][pt * 2 + fly_half], fly_bit, 1);
+        return __uint_as_float(__float_as_uint(x) & ~(unsigned)masked);
+    };
+    auto make_x = [&](int ch, int i) -> Split3 {
+        float xv[8];
+        if (fly) {
+            fly_cot[mb][lane] = cotr[i];
+            if (lane < 32) fly_msk[mb][lane] = mskr[i];
+            if (ch + XA < ch_end) load_fly(ch + XA, cotr[i], mskr[i]);
+            if (d.k == 4) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = fly_point(std::integral_constant<int, 4>{}, 8 * g + e);
+            } else if (d.k == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = fly_point(std::integral_constant<int, 3>{}, 8 * g + e);
+            } else if (d.k == 2) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = fly_point(std::integral_constant<int, 2>{}, 8 * g + e);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = fly_point(std::integral_constant<int, 1>{}, 8 * g + e);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[e] = xr[i][e];
+            if (ch + XA < ch_end) load_x(ch + XA, xr[i]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum += xv[e];
+        return split8<false>(xv);
+    };
     int it = 0;
+    Split3 xs = make_x(ch_begin, 0);
     for (int ch0 = ch_begin; ch0 < ch_end; ch0 += XA) {
 #pragma unroll
         for (int i = 0; i < XA; ++i) {           // ring position i is static: the stages stay in registers
@@ -895,13 +972,9 @@ deform_wgrad_split_kernel(WGradSK a) {
                     ys[nb].m = ybuf[cur][(nb * 3 + 1) * 64 + lane];
                     ys[nb].l = ybuf[cur][(nb * 3 + 2) * 64 + lane];
                 }
-                float xv[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { xv[e] = xr[i][e]; bsum += xv[e]; }
-                const Split3 xs = split8<false>(xv);
-                if (ch + XA < ch_end) load_x(ch + XA, xr[i]);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[nb] = mma_split(xs, ys[nb], acc[nb]);
+                if (ch + 1 < ch_end) xs = make_x(ch + 1, (i + 1) % XA);
                 if (ch + 1 < ch_end && mb < NB) {
                     ybuf[cur ^ 1][(mb * 3 + 0) * 64 + lane] = ystage.h;
                     ybuf[cur ^ 1][(mb * 3 + 1) * 64 + lane] = ystage.m;
