@@ -1106,7 +1106,8 @@ static size_t bwd_ysplit_floats(int matmul, int n) {
 // + DW0_SLABS private copies of dW0 (128 x 32) and db0 (128), + W2_SLABS copies of dW2 / db2
 static size_t bwd_yfeat_floats(int matmul, int n) {
     return matmul == FDGS_MATMUL_SPLIT_BF16
-               ? (size_t)48 * ((size_t)n + 16) + (size_t)DW0_SLABS * (DW * 32 + DW) + (size_t)W2_SLABS * W2_SLAB_FLOATS
+               ? (size_t)48 * ((size_t)n + 16) + (size_t)DW0_SLABS * (DW * 32 + DW) + (size_t)W2_SLABS * W2_SLAB_FLOATS +
+                     (size_t)(DW * DW + DW)                  // Q and T of the one-output head (opacity_fold_kernel)
                : 0;
 }
 // brick binning of the HexPlane backward, in 4-byte words: perm [n], brick_of [n] (16 bit, rounded up),
@@ -1388,7 +1389,9 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     const int chunk_pts = bwd_chunk_points(n);
     // private copies of the small dW2 / db2 accumulators (split mode), folded into the outputs after the loop
     float* w2_slabs = ws_yfeat + (size_t)48 * ((size_t)n + 16) + (size_t)DW0_SLABS * (DW * 32 + DW);
-    if (split && hipMemsetAsync(w2_slabs, 0, (size_t)W2_SLABS * W2_SLAB_FLOATS * sizeof(float), s) != hipSuccess)
+    float* op_q = w2_slabs + (size_t)W2_SLABS * W2_SLAB_FLOATS;      // Q [128][128], then T [128]
+    if (split && hipMemsetAsync(w2_slabs, 0, ((size_t)W2_SLABS * W2_SLAB_FLOATS + DW * DW + DW) * sizeof(float), s) !=
+                     hipSuccess)
         return FDGS_ELAUNCH;
     for (int c0 = 0; c0 < n; c0 += chunk_pts) {
         const int cn = (n - c0) < chunk_pts ? (n - c0) : chunk_pts;
@@ -1447,6 +1450,10 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                         w4.d[h].cot = kc.g[h]; w4.d[h].k = kdim[h]; w4.d[h].w2 = a->p.w2[h];
                         w4.d[h].mask = reinterpret_cast<const uint2*>(a->mask) + ((size_t)h * n + c0) * 2;
                     }
+                    if (h == 3) {           // one output: unit weights, raw sums into Q / T (folded after the loop)
+                        w4.d[h].w2 = nullptr;
+                        w4.d[h].C = op_q; w4.d[h].rowsum = op_q + DW * DW;
+                    }
                 }
             hipLaunchKernelGGL(deform_wgrad_split_kernel<4>, dim3((chunks + per - 1) / per, 5), dim3(256), 0, s, w4);
             FDGS_CHECK_LAUNCH();
@@ -1465,7 +1472,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                 cs.X[h] = kc.g[h]; cs.ncols[h] = kdim[h]; cs.out[h] = a->dp.b2[h];
             }
             w2k.tiles_per_block = tpb = (tiles + 1023) / 1024;       // about 1000 waves per launch
-            w2k.dw2_slabs = w2_slabs; w2k.slabs = W2_SLABS;
+            w2k.dw2_slabs = w2_slabs; w2k.slabs = W2_SLABS; w2k.small_heads = 3;
             cs.slabs_base = w2_slabs + (size_t)W2_SLABS * 59 * DW; cs.slabs = W2_SLABS;
             hipLaunchKernelGGL(deform_wgrad2_split_kernel<1>, dim3((tiles + tpb - 1) / tpb), dim3(64), 0, s, w2k);
             FDGS_CHECK_LAUNCH();
@@ -1499,6 +1506,11 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         FDGS_CHECK_LAUNCH();
     }
     if (split) {
+        OpacityFoldK of;
+        of.Q = op_q; of.T = op_q + DW * DW; of.w1 = a->p.w1[3]; of.b1 = a->p.b1[3]; of.w2 = a->p.w2[3];
+        of.dw1 = a->dp.w1[3]; of.db1 = a->dp.b1[3]; of.dw2 = a->dp.w2[3];
+        hipLaunchKernelGGL(opacity_fold_kernel, dim3(DW), dim3(DW), 0, s, of);
+        FDGS_CHECK_LAUNCH();
         static const int row0[5] = {0, 3, 6, 10, 11};
         SlabReduceK sr;
         for (int e = 0; e < SLAB_ENTRIES; ++e) { sr.slab[e] = nullptr; sr.out[e] = nullptr; sr.count[e] = 0; sr.stride[e] = 0; }

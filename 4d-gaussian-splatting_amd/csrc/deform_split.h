@@ -868,10 +868,10 @@ deform_wgrad_split_kernel(WGradSK a) {
     float cotr[XA];
     unsigned mskr[XA];
     float w2v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (fly) {
+    if (fly) {                                   // w2 == NULL: unit weights (X = mask * cot, k = 1)
 #pragma unroll
         for (int o = 0; o < 4; ++o)
-            if (o < d.k) w2v[o] = d.w2[o * DW + 32 * mb + c];
+            if (o < d.k) w2v[o] = d.w2 ? d.w2[o * DW + 32 * mb + c] : 1.0f;
     }
     // feature 32 mb + c sits in the mask of lane half (c >> 2) & 1, word mb >> 1, at bit 31 - (16 (mb & 1) + r)
     // with r = (c & 3) + 4 ((c >> 3) & 3)
@@ -1041,6 +1041,8 @@ struct WGrad2SK {
     // 11-58 shs): wave b adds into copy b % slabs (every wave hits every line of its heads, and atomics to one
     // line serialise in its L2 channel); wgrad_slab_reduce_kernel folds them into dw2.  NULL: straight into dw2
     float* dw2_slabs; int slabs;
+    int small_heads;                             // NOB = 1 walks heads 0 .. small_heads - 1 (3: the opacity head's dW2
+                                                 // comes from opacity_fold_kernel instead)
 };
 
 // NOB = 2: the shs head alone (48 rows = two row blocks).  NOB = 1: the four small heads TOGETHER, their
@@ -1057,7 +1059,7 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
     const int t_end = min(t_begin + a.tiles_per_block, total_tiles);
     if (t_begin >= t_end) return;
     const int ngroups = (a.n + 31) / 32;
-    const int head_first = NOB == 1 ? 0 : 4, head_last = NOB == 1 ? 3 : 4;
+    const int head_first = NOB == 1 ? 0 : 4, head_last = NOB == 1 ? a.small_heads - 1 : 4;
     floatx16 c2[NOB][4];
 #pragma unroll
     for (int ob = 0; ob < NOB; ++ob)
@@ -1163,6 +1165,32 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
                     }
                 }
             }
+}
+
+// A head with ONE output needs no recompute of h1 for its dW2.  With X[p][f] = [h1[p][f] > 0] g[p] (unit weights in
+// the dW1 product above) the kernel above yields Q[f][n] = sum_p X[p][f] relu(hidden)[p][n] and T[f] = sum_p X[p][f],
+// and, h1 being W1 relu(hidden) + b1 where the mask is set,
+//   dW1[f][n] = w2[f] Q[f][n],   db1[f] = w2[f] T[f],   dW2[f] = sum_n W1[f][n] Q[f][n] + b1[f] T[f].
+// One workgroup per row f.
+struct OpacityFoldK { const float* Q; const float* T; const float* w1; const float* b1; const float* w2;
+                      float* dw1; float* db1; float* dw2; };
+__global__ void __launch_bounds__(DW)
+opacity_fold_kernel(OpacityFoldK a) {
+    __shared__ float part[2];
+    const int f = blockIdx.x, n = threadIdx.x;
+    const float q = a.Q[f * DW + n];
+    const float w2f = a.w2[f];
+    if (a.dw1) a.dw1[f * DW + n] += w2f * q;
+    float s = a.w1[f * DW + n] * q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((n & 63) == 0) part[n >> 6] = s;
+    __syncthreads();
+    if (n == 0) {
+        const float t = a.T[f];
+        if (a.dw2) a.dw2[f] += part[0] + part[1] + a.b1[f] * t;
+        if (a.db1) a.db1[f] += w2f * t;
+    }
 }
 
 // column sums of a small row-major matrix: out[j] += sum_p X[p][j], j < ncols <= 64 (the b2 gradients)
