@@ -574,8 +574,9 @@ static size_t fwd_split_bias_floats() { return DW + 5 * DW + 5 * 64; }
 static size_t fwd_split_feat_floats(int n) { return (size_t)((n + 31) / 32) * 2 * 3 * 64 * 4; }
 
 static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
-    if ((a->save_hidden == nullptr) != (a->save_mask == nullptr) || (a->save_hidden == nullptr) != (a->save_act == nullptr))
-        return FDGS_EINVAL;                                                        // all three or none
+    const bool saving = a->save_mask != nullptr;
+    if (saving != (a->save_act != nullptr) || saving != (a->save_hidden != nullptr || a->save_yhid != nullptr))
+        return FDGS_EINVAL;                         // mask, act and (hidden or yhid) together, or none of them
     DeformFwdSK k;
     HexFeatSK g;
     k.n = g.n = a->num_points;
@@ -620,10 +621,11 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     k.save_hidden = a->save_hidden;
     k.save_act = reinterpret_cast<u32x4*>(a->save_act);
     k.save_mask = reinterpret_cast<uint2*>(a->save_mask);
+    k.save_yhid = reinterpret_cast<u32x4*>(a->save_yhid);
     hipLaunchKernelGGL(hexplane_features_split_kernel, dim3((a->num_points + 127) / 128), dim3(256), 0, s, g);
     FDGS_CHECK_LAUNCH();
     const int blocks = (a->num_points + 32 * SCB - 1) / (32 * SCB);
-    if (a->save_hidden) hipLaunchKernelGGL(deform_fwd_split_kernel<true>, dim3(blocks), dim3(64), 0, s, k);
+    if (saving) hipLaunchKernelGGL(deform_fwd_split_kernel<true>, dim3(blocks), dim3(64), 0, s, k);
     else hipLaunchKernelGGL(deform_fwd_split_kernel<false>, dim3(blocks), dim3(64), 0, s, k);
     FDGS_CHECK_LAUNCH();
     return FDGS_OK;
@@ -1151,7 +1153,7 @@ static SideStream* side_stream() {
 extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     if (!a || a->num_points < 0 || !params_ok(&a->p)) return FDGS_EINVAL;
     if (a->num_points == 0) return FDGS_OK;
-    if (!a->xyz || !a->hidden || !a->g_xyz || !a->g_scales || !a->g_rotations || !a->g_opacity || !a->g_shs ||
+    if (!a->xyz || (!a->hidden && !(a->yhid && a->p.matmul == FDGS_MATMUL_SPLIT_BF16)) || !a->g_xyz || !a->g_scales || !a->g_rotations || !a->g_opacity || !a->g_shs ||
         !a->d_xyz || !a->workspace)
         return FDGS_EINVAL;
     if (a->workspace_bytes < fdgs_deform_bwd_workspace_bytes(&a->p, a->num_points)) return FDGS_EWORKSPACE;
@@ -1426,15 +1428,19 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         if (split) {
             // dW1_h[m][n] = sum_p dh1_h[p][m] relu(hidden)[p][n]: relu(hidden) pre-split once, dh1 split on the fly
             const int chunks = (cn + 15) / 16;
-            u32x4* y_hidden = reinterpret_cast<u32x4*>(ws_ysplit);
-            WGradPrepK pk;
-            pk.n = cn;
-            pk.d[0] = WGradPrepDesc{kc.hidden, DW, DW, 4, 1, y_hidden, nullptr};
-            for (int i = 1; i < WPREP_MAX; ++i) pk.d[i] = pk.d[0];
-            int pblocks = (chunks + 3) / 4;
-            if (pblocks > 4096) pblocks = 4096;
-            hipLaunchKernelGGL(wgrad_prep_split_kernel, dim3(pblocks, 1), dim3(256), 0, s, pk);
-            FDGS_CHECK_LAUNCH();
+            const u32x4* y_hidden = reinterpret_cast<const u32x4*>(ws_ysplit);
+            if (a->yhid) {                      // written by the forward: chunk c0 / 16 onwards
+                y_hidden = reinterpret_cast<const u32x4*>(a->yhid) + (size_t)(c0 / 16) * 4 * 3 * 64;
+            } else {
+                WGradPrepK pk;
+                pk.n = cn;
+                pk.d[0] = WGradPrepDesc{kc.hidden, DW, DW, 4, 1, reinterpret_cast<u32x4*>(ws_ysplit), nullptr};
+                for (int i = 1; i < WPREP_MAX; ++i) pk.d[i] = pk.d[0];
+                int pblocks = (chunks + 3) / 4;
+                if (pblocks > 4096) pblocks = 4096;
+                hipLaunchKernelGGL(wgrad_prep_split_kernel, dim3(pblocks, 1), dim3(256), 0, s, pk);
+                FDGS_CHECK_LAUNCH();
+            }
             int per = (chunks + 203) / 204;     // about a thousand workgroups of four waves
             if (per < 4) per = 4;
             WGradSK w4;

@@ -420,6 +420,8 @@ struct DeformFwdSK {
     float* save_hidden;                              // optional [n,128]: hidden, pre-activation
     u32x4* save_act;                                 // relu(hidden) as split operand pieces: [ceil(n/32)][8][3][64]
     uint2* save_mask;                                // optional [6][n][2]: ReLU masks of the heads' h1 and of hidden
+    u32x4* save_yhid;                                // optional: relu(hidden) split, points-as-K order (the B operand of
+                                                     // the dW1 products): [ceil(n/16)][4][3][64]
 };
 
 // hidden^T = W0 f^T + b0 for the SCB point groups of this wave
@@ -470,13 +472,49 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             const int p = base + 32 * cb + c;
             if (p < a.n) {
                 a.save_mask[((size_t)5 * a.n + p) * 2 + h] = relu_mask_build(hid[cb]);
+                if (a.save_hidden) {
+#pragma unroll
+                    for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            *reinterpret_cast<float4*>(a.save_hidden + (size_t)p * DW + 32 * nb + 8 * q + 4 * h) =
+                                make_float4(hid[cb][nb][4 * q], hid[cb][nb][4 * q + 1], hid[cb][nb][4 * q + 2],
+                                            hid[cb][nb][4 * q + 3]);
+                }
+            }
+        }
+        if (a.save_yhid) {
+            // relu(hidden) once more, transposed: the dW1 products of the backward contract over the POINTS, so
+            // their operand needs eight consecutive points of one feature per lane.  32 points x 128 features go
+            // through an LDS tile (row = feature, 36 floats: 16-byte aligned, conflict-free for both accesses);
+            // lane (n, kg) then reads points 8 kg .. 8 kg + 7 of feature 32 nb + n for each 16-point chunk.
+            __shared__ __attribute__((aligned(16))) float ytile[DW * 36];
+            const int total_chunks = (a.n + 15) / 16;
+#pragma unroll
+            for (int cb = 0; cb < SCB; ++cb) {
+                const bool ok = base + 32 * cb + c < a.n;
+                __syncthreads();
 #pragma unroll
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        *reinterpret_cast<float4*>(a.save_hidden + (size_t)p * DW + 32 * nb + 8 * q + 4 * h) =
-                            make_float4(hid[cb][nb][4 * q], hid[cb][nb][4 * q + 1], hid[cb][nb][4 * q + 2],
-                                        hid[cb][nb][4 * q + 3]);
+                    for (int r = 0; r < 16; ++r)
+                        ytile[(32 * nb + drow(r, h)) * 36 + c] = ok ? hid[cb][nb][r] : 0.0f;
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int chunk = (base + 32 * cb) / 16 + q;
+                    if (chunk < total_chunks) {
+#pragma unroll
+                        for (int nb = 0; nb < 4; ++nb) {
+                            const float4* src = reinterpret_cast<const float4*>(ytile + (32 * nb + c) * 36 + 16 * q + 8 * h);
+                            const float4 v0 = src[0], v1 = src[1];
+                            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                            const Split3 s3 = split8<true>(v);
+                            u32x4* dst = a.save_yhid + (size_t)((chunk * 4 + nb) * 3) * 64 + lane;
+                            dst[0] = s3.h; dst[64] = s3.m; dst[128] = s3.l;
+                        }
+                    }
+                }
             }
         }
     }

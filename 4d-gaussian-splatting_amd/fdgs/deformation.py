@@ -222,29 +222,32 @@ class _DeformFunction(torch.autograd.Function):
         # needs_input_grad is also set under torch.no_grad(); the caller's grad mode decides whether
         # the activations are saved (0.92 GB at 300k points)
         need_grad = grad_mode and any(ctx.needs_input_grad)
-        hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if need_grad else None
         split_saves = need_grad and MATMUL == _lib.MATMUL_SPLIT_BF16
-        # relu(hidden) as operand pieces (768 B/point) and the ReLU bit masks (96 B/point); relu(h1) is recomputed
+        # fp32-MFMA mode keeps hidden [N,128]; split mode keeps relu(hidden) twice as operand pieces (768 B/point
+        # each: lane = point for the dW2 recompute, points-as-K for the dW1 products) and the ReLU bit masks
+        # (96 B/point); relu(h1) is recomputed
+        hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if (need_grad and not split_saves) else None
         act = torch.empty((N + 31) // 32 * 32, 192, device=dev, dtype=torch.float32) if split_saves else None
+        yhid = torch.empty((N + 15) // 16 * 16 + 16, 192, device=dev, dtype=torch.float32) if split_saves else None
         mask = torch.empty(N, 12, device=dev, dtype=torch.int64) if split_saves else None
         P = _fill_params(net)
         ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), time_scalar,
                                ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(outs[4]), ptr(hidden),
-                               ptr(act), ptr(mask), ptr(ws), ws_bytes)
+                               ptr(act), ptr(mask), ptr(yhid), ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_fwd", a)
         ctx.net = net
         ctx.time_scalar = time_scalar
         ctx.param_versions = [p._version for p in params]
         ctx.matmul = MATMUL
-        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act, mask)
+        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act, mask, yhid)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_xyz, g_sc, g_ro, g_op, g_sh):
         net = ctx.net
-        xyz_c, time_c, hidden, fwd_ws, act, mask = ctx.saved_tensors
+        xyz_c, time_c, hidden, fwd_ws, act, mask, yhid = ctx.saved_tensors
         N = xyz_c.shape[0]
         dev = xyz_c.device
         def c(t, shape):
@@ -269,7 +272,7 @@ class _DeformFunction(torch.autograd.Function):
         planes_cl = ptr(fwd_ws) if unchanged else None
         ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
+        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), ptr(yhid), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
         g_sh_out, pending = g_sh, None
         if RESIDUAL_GRAD_HOOK is not None:

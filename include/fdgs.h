@@ -237,6 +237,11 @@ typedef struct {
     /*   mask, 96 bytes per point (12 N 64-bit words): the ReLU decisions of hidden and of the five heads;
      *   required together with save_hidden when p.matmul == FDGS_MATMUL_SPLIT_BF16, unused otherwise */
     void* save_mask;
+    /*   yhid, 768 bytes per point for ceil(N/16)*16 + 16 points: relu(hidden) once more as split pieces, in the
+     *   points-as-K order of the backward's dW1 products (layout private to the library).  Optional
+     *   (FDGS_MATMUL_SPLIT_BF16 only): with it the backward skips its own conversion pass and save_hidden may
+     *   be NULL                                                                                        */
+    void* save_yhid;
     void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
 } fdgs_deform_fwd_args;
@@ -249,9 +254,10 @@ typedef struct {
     fdgs_deform_params p;
     const float* xyz;
     const float* time; float time_scalar;
-    const float* hidden;             /* [N,128] saved by the forward                */
+    const float* hidden;             /* [N,128] saved by the forward; may be NULL when yhid is given */
     const void* act;                 /* saved by the forward (SPLIT_BF16 only, else may be NULL) */
     const void* mask;                /* 96 N bytes saved by the forward (SPLIT_BF16 only, else may be NULL) */
+    const void* yhid;                /* the forward's save_yhid (SPLIT_BF16 only), or NULL: rebuilt from hidden */
     const float* planes_channel_last;/* the forward's workspace (channel-last plane copies) if the parameters have
                                         not changed since, else NULL: the copies are rebuilt inside the workspace */
     /* output cotangents; the residual inputs (scales, rotations, opacity, shs)
