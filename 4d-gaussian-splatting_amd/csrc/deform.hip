@@ -612,7 +612,7 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
         if (rc != FDGS_OK) return rc;
     }
     g.aabb = a->p.aabb; g.xyz = a->xyz; g.time = a->time; g.time_scalar = a->time_scalar;
-    g.feat_split = feat; g.feat_f32 = nullptr;
+    g.feat_split = feat; g.feat_f32 = nullptr; g.feat_y = reinterpret_cast<u32x4*>(a->save_yfeat);
     k.feat_split = feat;
     k.in[0] = a->xyz; k.in[1] = a->scales; k.in[2] = a->rotations; k.in[3] = a->opacity; k.in[4] = a->shs;
     k.out[0] = a->out_xyz; k.out[1] = a->out_scales; k.out[2] = a->out_rotations; k.out[3] = a->out_opacity;
@@ -660,7 +660,7 @@ extern "C" int fdgs_hexplane_features(const fdgs_hexplane_features_args* a, void
     if (rc != FDGS_OK) return rc;
     g.aabb = a->p.aabb; g.xyz = a->xyz; g.time = a->time; g.time_scalar = a->time_scalar;
     g.feat_split = reinterpret_cast<u32x4*>(ws + total_plane_floats(&a->p));
-    g.feat_f32 = a->features;
+    g.feat_f32 = a->features; g.feat_y = nullptr;
     hipLaunchKernelGGL(hexplane_features_split_kernel, dim3((a->num_points + 127) / 128), dim3(256), 0, s, g);
     FDGS_CHECK_LAUNCH();
     return FDGS_OK;
@@ -873,7 +873,7 @@ struct HexBwdK {
     const float* aabb;
     const float* xyz; const float* time; float time_scalar;
     const float* ws_df;                  // [N,32] dL/dfeature
-    float* ws_feat;                      // [N,32] features (for the first Linear's weight gradient)
+    float* ws_feat;                      // [N,32] features, or NULL (for the first Linear's weight gradient)
     const float* g_xyz; float* d_xyz;
     int lds_time;                        // 1: one time stamp for all points, time-plane rows live in LDS
 };
@@ -940,7 +940,7 @@ hexplane_bwd_kernel(HexBwdK a, int lds_floats) {
         }
         float dfv = 0.0f;
         if (valid) {
-            a.ws_feat[(size_t)p * 32 + 16 * h + ch] = feat;
+            if (a.ws_feat) a.ws_feat[(size_t)p * 32 + 16 * h + ch] = feat;
             dfv = a.ws_df[(size_t)p * 32 + 16 * h + ch];
         }
         float dco[3] = {0.f, 0.f, 0.f};
@@ -1239,11 +1239,53 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     k.g[0] = a->g_xyz; k.g[1] = a->g_scales; k.g[2] = a->g_rotations; k.g[3] = a->g_opacity; k.g[4] = a->g_shs;
     k.ws_a1 = ws_a1; k.ws_dh1 = ks.ws_dh1 = ws_dh1; k.ws_dhid = ks.ws_dhid = ws_dhid;
     k.ws_df = ks.ws_df = ws_df;
+    // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f], db0 = column sums of dhid (split mode): the same split product as
+    // the dW1 kernels with one 32-column block.  yfeat: the features as points-as-K pieces from the forward, or
+    // NULL to build them from ws_feat (written by the HexPlane backward, so only after it).
+    auto launch_dw0_split = [&](hipStream_t hs, const u32x4* yfeat) -> int {
+        const int chunks = (n + 15) / 16;
+        if (!yfeat) {
+            WGradPrepK pk;
+            pk.n = n;
+            pk.d[0] = WGradPrepDesc{ws_feat, 32, 32, 1, 0, reinterpret_cast<u32x4*>(ws_yfeat), nullptr};
+            for (int i = 1; i < WPREP_MAX; ++i) pk.d[i] = pk.d[0];
+            int pblocks = (chunks + 3) / 4;
+            if (pblocks > 4096) pblocks = 4096;
+            hipLaunchKernelGGL(wgrad_prep_split_kernel, dim3(pblocks, 1), dim3(256), 0, hs, pk);
+            FDGS_CHECK_LAUNCH();
+            yfeat = reinterpret_cast<const u32x4*>(ws_yfeat);
+        }
+        int per = (chunks + 1023) / 1024;
+        if (per < 4) per = 4;
+        WGradSK w1;
+        w1.n = n;
+        w1.chunks_per_block = per;
+        for (int i = 0; i < WGS_MAX; ++i) w1.d[i].C = nullptr;
+        // dW0 is 128 rows of 128 bytes: every workgroup would hit every one of them; private copies instead
+        float* slab_w = ws_yfeat + (size_t)48 * ((size_t)n + 16);
+        float* slab_b = slab_w + (size_t)DW0_SLABS * DW * 32;
+        if (hipMemsetAsync(slab_w, 0, (size_t)DW0_SLABS * (DW * 32 + DW) * sizeof(float), hs) != hipSuccess)
+            return FDGS_ELAUNCH;
+        w1.d[0] = WGradSDesc{ws_dhid, DW, yfeat, slab_w, 32, 1, 32,
+                             a->dp.b0 ? slab_b : nullptr, DW0_SLABS, DW * 32, DW, nullptr, 0, nullptr, nullptr};
+        if (!a->dp.w0) w1.d[0].C = nullptr;
+        hipLaunchKernelGGL(deform_wgrad_split_kernel<1>, dim3((chunks + per - 1) / per, 1), dim3(256), 0, hs, w1);
+        FDGS_CHECK_LAUNCH();
+        SlabReduceK sr;
+        for (int e = 0; e < SLAB_ENTRIES; ++e) { sr.slab[e] = nullptr; sr.out[e] = nullptr; sr.count[e] = 0; sr.stride[e] = 0; }
+        sr.slab[0] = slab_w; sr.out[0] = a->dp.w0; sr.count[0] = DW * 32; sr.stride[0] = DW * 32;
+        sr.slab[1] = slab_b; sr.out[1] = a->dp.w0 ? a->dp.b0 : nullptr; sr.count[1] = DW; sr.stride[1] = DW;
+        sr.slabs = DW0_SLABS;
+        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(DW * 32 / 256, 2), dim3(256), 0, hs, sr);
+        FDGS_CHECK_LAUNCH();
+        return FDGS_OK;
+    };
     // pass 1b + dW0 + plane-gradient layout change: everything downstream of dfeat; runs on stream hs
     auto hex_tail = [&](hipStream_t hs) -> int {
         // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
         hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
-        hk.ws_df = ws_df; hk.ws_feat = ws_feat; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
+        hk.ws_df = ws_df; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
+        hk.ws_feat = (a->yfeat && a->p.matmul == FDGS_MATMUL_SPLIT_BF16) ? nullptr : ws_feat;
         hk.lds_time = (a->time == nullptr) ? 1 : 0;
         // brick path: float64 windows of all twelve planes in LDS; the coarsest brick grid whose windows fit
         HexBrickK bk;
@@ -1316,40 +1358,10 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             FDGS_CHECK_LAUNCH();
         }
         if (a->p.matmul == FDGS_MATMUL_SPLIT_BF16) {
-            // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f], db0 = column sums of dhid: the same split product as
-            // the dW1 kernels, with one 32-column block (features pre-split in points-as-K order first)
-            const int chunks = (n + 15) / 16;
-            WGradPrepK pk;
-            pk.n = n;
-            pk.d[0] = WGradPrepDesc{ws_feat, 32, 32, 1, 0, reinterpret_cast<u32x4*>(ws_yfeat), nullptr};
-            for (int i = 1; i < WPREP_MAX; ++i) pk.d[i] = pk.d[0];
-            int pblocks = (chunks + 3) / 4;
-            if (pblocks > 4096) pblocks = 4096;
-            hipLaunchKernelGGL(wgrad_prep_split_kernel, dim3(pblocks, 1), dim3(256), 0, hs, pk);
-            FDGS_CHECK_LAUNCH();
-            int per = (chunks + 1023) / 1024;
-            if (per < 4) per = 4;
-            WGradSK w1;
-            w1.n = n;
-            w1.chunks_per_block = per;
-            for (int i = 0; i < WGS_MAX; ++i) w1.d[i].C = nullptr;
-            // dW0 is 128 rows of 128 bytes: every workgroup would hit every one of them; private copies instead
-            float* slab_w = ws_yfeat + (size_t)48 * ((size_t)n + 16);
-            float* slab_b = slab_w + (size_t)DW0_SLABS * DW * 32;
-            if (hipMemsetAsync(slab_w, 0, (size_t)DW0_SLABS * (DW * 32 + DW) * sizeof(float), hs) != hipSuccess)
-                return FDGS_ELAUNCH;
-            w1.d[0] = WGradSDesc{ws_dhid, DW, reinterpret_cast<const u32x4*>(ws_yfeat), slab_w, 32, 1, 32,
-                                 a->dp.b0 ? slab_b : nullptr, DW0_SLABS, DW * 32, DW, nullptr, 0, nullptr, nullptr};
-            if (!a->dp.w0) w1.d[0].C = nullptr;
-            hipLaunchKernelGGL(deform_wgrad_split_kernel<1>, dim3((chunks + per - 1) / per, 1), dim3(256), 0, hs, w1);
-            FDGS_CHECK_LAUNCH();
-            SlabReduceK sr;
-            for (int e = 0; e < SLAB_ENTRIES; ++e) { sr.slab[e] = nullptr; sr.out[e] = nullptr; sr.count[e] = 0; sr.stride[e] = 0; }
-            sr.slab[0] = slab_w; sr.out[0] = a->dp.w0; sr.count[0] = DW * 32; sr.stride[0] = DW * 32;
-            sr.slab[1] = slab_b; sr.out[1] = a->dp.w0 ? a->dp.b0 : nullptr; sr.count[1] = DW; sr.stride[1] = DW;
-            sr.slabs = DW0_SLABS;
-            hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(DW * 32 / 256, 2), dim3(256), 0, hs, sr);
-            FDGS_CHECK_LAUNCH();
+            if (!a->yfeat) {                        // with the forward's pieces this product is already on its way
+                rc = launch_dw0_split(hs, nullptr);
+                if (rc != FDGS_OK) return rc;
+            }
         } else {                                    // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f]  (fp32 MFMA)
             WGradK w;
             w.n = n;
@@ -1423,6 +1435,10 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                 rc = hex_tail(side->stream);
                 if (rc != FDGS_OK) return rc;
                 if (hipEventRecord(side->join, side->stream) != hipSuccess) return FDGS_ELAUNCH;
+            }
+            if (split && a->yfeat) {            // needs dhid only: runs beside the HexPlane backward, not after it
+                rc = launch_dw0_split(s, reinterpret_cast<const u32x4*>(a->yfeat));
+                if (rc != FDGS_OK) return rc;
             }
         }
         if (split) {

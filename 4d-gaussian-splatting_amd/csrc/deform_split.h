@@ -302,6 +302,8 @@ struct HexFeatSK {
     const float* xyz; const float* time; float time_scalar;
     u32x4* feat_split;                   // [ceil(n/32)][2][3][64]
     float* feat_f32;                     // optional [n,32]
+    u32x4* feat_y;                       // optional: the features split, points-as-K order (B operand of the dW0
+                                         // product of the backward): [ceil(n/16)][3][64]
 };
 
 #define HF_PTS 128                       // points per workgroup (4 waves x 32)
@@ -351,6 +353,27 @@ hexplane_features_split_kernel(HexFeatSK a) {
     }
     __syncthreads();
     const int c = lane & 31, h = lane >> 5;
+    if (a.feat_y) {
+        // the same tile read the other way: lane (feature c, half h) takes points 8 h .. 8 h + 7 of a 16-point
+        // chunk; two chunks per wave.  Points beyond n contribute zeros.
+        const int total_chunks = (a.n + 15) / 16;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int lc = wave * 2 + q;                     // chunk within the workgroup's 128 points
+            const int chunk = blockIdx.x * (HF_PTS / 16) + lc;
+            if (chunk < total_chunks) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int pl = 16 * lc + 8 * h + e;
+                    v[e] = (blockIdx.x * HF_PTS + pl < a.n) ? tile[pl * HF_STRIDE + c] : 0.0f;
+                }
+                const Split3 s3 = split8<false>(v);
+                u32x4* dst = a.feat_y + (size_t)(chunk * 3) * 64 + lane;
+                dst[0] = s3.h; dst[64] = s3.m; dst[128] = s3.l;
+            }
+        }
+    }
     const int G = blockIdx.x * 4 + wave;
     if (G * 32 >= a.n) return;
     const int p = G * 32 + c;

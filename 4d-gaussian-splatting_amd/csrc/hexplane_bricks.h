@@ -233,7 +233,7 @@ hexplane_bwd_brick_kernel(HexBrickK k, int lds_floats) {
             ddy[ci] = (t10 - t00) * (1.0f - fx) + (t11 - t01) * fx;
             feat *= v[ci];
         }
-        if (valid) a.ws_feat[(size_t)p * 32 + 16 * h + ch] = feat;
+        if (valid && a.ws_feat) a.ws_feat[(size_t)p * 32 + 16 * h + ch] = feat;
 #pragma unroll
         for (int ci = 0; ci < 6; ++ci) {
             const int ax = plane_a(ci), bx = plane_b(ci);

@@ -86,12 +86,12 @@ class DeformFwdArgs(C.Structure):
                 ("xyz", c_p), ("scales", c_p), ("rotations", c_p), ("opacity", c_p), ("shs", c_p),
                 ("time", c_p), ("time_scalar", c_f),
                 ("out_xyz", c_p), ("out_scales", c_p), ("out_rotations", c_p), ("out_opacity", c_p),
-                ("out_shs", c_p), ("save_hidden", c_p), ("save_act", c_p), ("save_mask", c_p), ("save_yhid", c_p), ("workspace", c_p), ("workspace_bytes", c_sz)]
+                ("out_shs", c_p), ("save_hidden", c_p), ("save_act", c_p), ("save_mask", c_p), ("save_yhid", c_p), ("save_yfeat", c_p), ("workspace", c_p), ("workspace_bytes", c_sz)]
 
 
 class DeformBwdArgs(C.Structure):
     _fields_ = [("num_points", c_i32), ("p", DeformParams),
-                ("xyz", c_p), ("time", c_p), ("time_scalar", c_f), ("hidden", c_p), ("act", c_p), ("mask", c_p), ("yhid", c_p), ("planes_channel_last", c_p),
+                ("xyz", c_p), ("time", c_p), ("time_scalar", c_f), ("hidden", c_p), ("act", c_p), ("mask", c_p), ("yhid", c_p), ("yfeat", c_p), ("planes_channel_last", c_p),
                 ("g_xyz", c_p), ("g_scales", c_p), ("g_rotations", c_p), ("g_opacity", c_p), ("g_shs", c_p),
                 ("d_xyz", c_p), ("dp", DeformParamGrads), ("workspace", c_p), ("workspace_bytes", c_sz)]
 
@@ -162,7 +162,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 def _load():

@@ -230,24 +230,25 @@ class _DeformFunction(torch.autograd.Function):
         act = torch.empty((N + 31) // 32 * 32, 192, device=dev, dtype=torch.float32) if split_saves else None
         yhid = torch.empty((N + 15) // 16 * 16 + 16, 192, device=dev, dtype=torch.float32) if split_saves else None
         mask = torch.empty(N, 12, device=dev, dtype=torch.int64) if split_saves else None
+        yfeat = torch.empty((N + 15) // 16 * 16 + 16, 48, device=dev, dtype=torch.float32) if split_saves else None
         P = _fill_params(net)
         ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), time_scalar,
                                ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(outs[4]), ptr(hidden),
-                               ptr(act), ptr(mask), ptr(yhid), ptr(ws), ws_bytes)
+                               ptr(act), ptr(mask), ptr(yhid), ptr(yfeat), ptr(ws), ws_bytes)
         _lib.call("fdgs_deform_fwd", a)
         ctx.net = net
         ctx.time_scalar = time_scalar
         ctx.param_versions = [p._version for p in params]
         ctx.matmul = MATMUL
-        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act, mask, yhid)
+        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act, mask, yhid, yfeat)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_xyz, g_sc, g_ro, g_op, g_sh):
         net = ctx.net
-        xyz_c, time_c, hidden, fwd_ws, act, mask, yhid = ctx.saved_tensors
+        xyz_c, time_c, hidden, fwd_ws, act, mask, yhid, yfeat = ctx.saved_tensors
         N = xyz_c.shape[0]
         dev = xyz_c.device
         def c(t, shape):
@@ -272,7 +273,7 @@ class _DeformFunction(torch.autograd.Function):
         planes_cl = ptr(fwd_ws) if unchanged else None
         ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
-        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), ptr(yhid), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
+        a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), ptr(yhid), ptr(yfeat), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
                                ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
         g_sh_out, pending = g_sh, None
         if RESIDUAL_GRAD_HOOK is not None:

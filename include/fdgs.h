@@ -242,6 +242,10 @@ typedef struct {
      *   (FDGS_MATMUL_SPLIT_BF16 only): with it the backward skips its own conversion pass and save_hidden may
      *   be NULL                                                                                        */
     void* save_yhid;
+    /*   yfeat, 192 bytes per point for ceil(N/16)*16 + 16 points: the plane features as split pieces in the same
+     *   points-as-K order (operand of the first layer's weight gradient).  Optional (FDGS_MATMUL_SPLIT_BF16 only):
+     *   with it that product neither waits for the HexPlane backward nor needs the features recomputed  */
+    void* save_yfeat;
     void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
 } fdgs_deform_fwd_args;
@@ -258,6 +262,7 @@ typedef struct {
     const void* act;                 /* saved by the forward (SPLIT_BF16 only, else may be NULL) */
     const void* mask;                /* 96 N bytes saved by the forward (SPLIT_BF16 only, else may be NULL) */
     const void* yhid;                /* the forward's save_yhid (SPLIT_BF16 only), or NULL: rebuilt from hidden */
+    const void* yfeat;               /* the forward's save_yfeat (SPLIT_BF16 only), or NULL: recomputed */
     const float* planes_channel_last;/* the forward's workspace (channel-last plane copies) if the parameters have
                                         not changed since, else NULL: the copies are rebuilt inside the workspace */
     /* output cotangents; the residual inputs (scales, rotations, opacity, shs)
