@@ -125,6 +125,38 @@ class PlaneRegArgs(C.Structure):
                 ("loss", c_p), ("loss_partial", c_p)]
 
 
+CLS_KEEP, CLS_CLONE, CLS_SPLIT, CLS_DROP = 0, 1, 2, 3
+SURGERY_MAX_ARRAYS = 24
+SURGERY_ZERO_NEW = 1
+
+
+class DensifyClassifyArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("xyz_gradient_accum", c_p), ("denom", c_p), ("scaling", c_p),
+                ("grad_threshold", c_f), ("size_limit", c_f), ("cls", c_p)]
+
+
+class PruneClassifyArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("opacity", c_p), ("max_radii2D", c_p), ("scaling", c_p),
+                ("min_opacity", c_f), ("max_screen_size", c_f), ("world_limit", c_f), ("cls", c_p)]
+
+
+class SurgeryPlanArgs(C.Structure):
+    _fields_ = [("num_points", c_i32), ("cls", c_p), ("src", c_p), ("counts", c_p),
+                ("workspace", c_p), ("workspace_bytes", c_sz)]
+
+
+class SurgeryApplyArgs(C.Structure):
+    _fields_ = [("rows_after", c_i32), ("rows_carried", c_i32), ("src", c_p), ("num_arrays", c_i32),
+                ("in_", c_p * SURGERY_MAX_ARRAYS), ("out", c_p * SURGERY_MAX_ARRAYS),
+                ("row_bytes", c_i32 * SURGERY_MAX_ARRAYS), ("flags", c_i32 * SURGERY_MAX_ARRAYS)]
+
+
+class SplitChildrenArgs(C.Structure):
+    _fields_ = [("num_children", c_i32), ("first_child_row", c_i32), ("src", c_p),
+                ("xyz", c_p), ("scaling", c_p), ("rotation", c_p), ("noise", c_p),
+                ("xyz_out", c_p), ("scaling_out", c_p)]
+
+
 ADAM_MAX_TENSORS = 48
 
 
@@ -159,6 +191,13 @@ SYMBOLS = {
     "fdgs_plane_regulation": (C.c_int, [C.POINTER(PlaneRegArgs), c_p]),
     "fdgs_knn_mean_dist2": (C.c_int, [c_p, c_i32, c_p, c_p]),
     "fdgs_adam_step": (C.c_int, [C.POINTER(AdamArgs), c_p]),
+    "fdgs_densify_classify": (C.c_int, [C.POINTER(DensifyClassifyArgs), c_p]),
+    "fdgs_prune_classify": (C.c_int, [C.POINTER(PruneClassifyArgs), c_p]),
+    "fdgs_surgery_workspace_bytes": (c_sz, [c_i32]),
+    "fdgs_surgery_plan": (C.c_int, [C.POINTER(SurgeryPlanArgs), c_p]),
+    "fdgs_surgery_apply": (C.c_int, [C.POINTER(SurgeryApplyArgs), c_p]),
+    "fdgs_split_children": (C.c_int, [C.POINTER(SplitChildrenArgs), c_p]),
+    "fdgs_reset_opacity": (C.c_int, [c_p, c_i32, c_f, c_p]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 

@@ -46,11 +46,7 @@ class TrainStep:
             self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
-        self.params = [p for grp in groups for p in grp["params"]]
-        self.bucket = dp.GradBucket(self.params)
-        # the SH gradients can be exchanged early (fdgs.deformation.RESIDUAL_GRAD_HOOK); the rest then goes here
-        sh_ids = {id(gaussians._features_dc), id(gaussians._features_rest)}
-        self.bucket_without_sh = dp.GradBucket([p for p in self.params if id(p) not in sh_ids])
+        self._bind_parameters()
         self.early_exchange = os.environ.get("FDGS_DP_EARLY", "1") != "0"
         dp.broadcast_parameters(self.params)      # replicas start identical whatever the ranks' RNG state was
         n = gaussians._xyz.shape[0]
@@ -59,6 +55,40 @@ class TrainStep:
         self.denom = torch.zeros(n, 1, device=dev)
         self.max_radii2D = torch.zeros(n, device=dev)
         self.fused_tail = on_gpu            # L1 loss and densification statistics as single libfdgs passes
+
+    def _bind_parameters(self):
+        """The flat parameter list and the gradient buckets of the tensors the optimizer holds now."""
+        self.params = [p for grp in self.optimizer.param_groups for p in grp["params"]]
+        self.bucket = dp.GradBucket(self.params)
+        # the SH gradients can be exchanged early (fdgs.deformation.RESIDUAL_GRAD_HOOK); the rest then goes here
+        sh_ids = {id(self.g._features_dc), id(self.g._features_rest)}
+        self.bucket_without_sh = dp.GradBucket([p for p in self.params if id(p) not in sh_ids])
+
+    # -- densification / pruning between steps (fdgs_trainer.py:191-200) --------------------------------
+    def surgery(self, percent_dense=0.01):
+        from .densify import GaussianSurgery
+
+        def noise(count, device):       # every replica must place the split children identically
+            t = torch.randn(count, 3, device=device, dtype=torch.float32)
+            dp.broadcast_parameters([t])
+            return t
+        deforms = self.deforms if hasattr(self.deforms, "deformation_table") else None
+        return GaussianSurgery(self.g, self.optimizer, deforms=deforms, stats=self, percent_dense=percent_dense,
+                               noise_fn=noise)
+
+    def densify(self, max_grad, extent, noise=None, percent_dense=0.01):
+        out = self.surgery(percent_dense).densify(max_grad, extent, noise=noise)
+        self._bind_parameters()
+        return out
+
+    def prune(self, min_opacity, extent, max_screen_size, percent_dense=0.01):
+        out = self.surgery(percent_dense).prune(min_opacity, extent, max_screen_size)
+        self._bind_parameters()
+        return out
+
+    def reset_opacity(self):
+        self.surgery().reset_opacity()
+        self._bind_parameters()
 
     @torch.no_grad()
     def _stats_torch(self, radii, vis, vgrad):

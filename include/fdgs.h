@@ -378,6 +378,100 @@ typedef struct {
 
 int fdgs_adam_step(const fdgs_adam_args* a, void* stream);
 
+/* ---- densification / pruning surgery ------------------------------------------------------------
+ * The reference grows and shrinks the six per-Gaussian parameter tensors, their Adam moments and the
+ * per-Gaussian statistics with chains of boolean-mask indexing and torch.cat
+ * (src/runner/fdgs_trainer.py:304-366 optimizer surgery, :368-386 prune, :388-424 split, :426-449 clone,
+ * :451-475 postfix, :477-492 prune / densify drivers).  Here: classify every Gaussian in one pass, turn the
+ * classes into a row map with a stable three-way scan, and move every array through that map in one launch.
+ *
+ * Row order of the result (the order the reference's clone -> split -> prune sequence produces):
+ *   [ survivors (classes KEEP and CLONE), in their old order | copies of the CLONE rows |
+ *     first children of the SPLIT rows | second children of the SPLIT rows ]
+ * SPLIT parents and DROP rows disappear.                                                              */
+#define FDGS_CLS_KEEP 0
+#define FDGS_CLS_CLONE 1
+#define FDGS_CLS_SPLIT 2
+#define FDGS_CLS_DROP 3
+
+/* Classes for one densification (fdgs_trainer.py:487-492 with :426-430 and :392-397):
+ * g = xyz_gradient_accum / denom, NaN -> 0;  big = max(exp(scaling)) > size_limit (percent_dense * extent);
+ * CLONE if |g| >= grad_threshold and not big; SPLIT if g >= grad_threshold and big; else KEEP.        */
+typedef struct {
+    int32_t num_points;
+    const float* xyz_gradient_accum;   /* [N] */
+    const float* denom;                /* [N] */
+    const float* scaling;              /* [N,3] log-space */
+    float grad_threshold;
+    float size_limit;
+    uint8_t* cls;                      /* [N] out */
+} fdgs_densify_classify_args;
+int fdgs_densify_classify(const fdgs_densify_classify_args* a, void* stream);
+
+/* Classes for one pruning pass (fdgs_trainer.py:477-484): DROP if sigmoid(opacity) < min_opacity, or - when
+ * max_screen_size > 0 - if max_radii2D > max_screen_size or max(exp(scaling)) > world_limit (0.1 * extent);
+ * else KEEP.                                                                                          */
+typedef struct {
+    int32_t num_points;
+    const float* opacity;              /* [N] logits */
+    const float* max_radii2D;          /* [N]; may be NULL when max_screen_size <= 0 */
+    const float* scaling;              /* [N,3] log-space; may be NULL when max_screen_size <= 0 */
+    float min_opacity;
+    float max_screen_size;             /* <= 0: the size tests are off (the reference's None) */
+    float world_limit;
+    uint8_t* cls;                      /* [N] out */
+} fdgs_prune_classify_args;
+int fdgs_prune_classify(const fdgs_prune_classify_args* a, void* stream);
+
+/* Row map of the result.  src[r] = old row that new row r is taken from, for r < counts[0] <= 2 N.
+ * counts (device, 4 x int32): {rows after, survivors, clones, splits}.                              */
+typedef struct {
+    int32_t num_points;
+    const uint8_t* cls;                /* [N] */
+    int32_t* src;                      /* [2 N] out */
+    int32_t* counts;                   /* [4] out */
+    void* workspace; size_t workspace_bytes;   /* fdgs_surgery_workspace_bytes(N) */
+} fdgs_surgery_plan_args;
+size_t fdgs_surgery_workspace_bytes(int32_t num_points);
+int fdgs_surgery_plan(const fdgs_surgery_plan_args* a, void* stream);
+
+/* Moves up to 24 row-major arrays through the map in one launch: out[r] = in[src[r]].  Arrays flagged
+ * FDGS_SURGERY_ZERO_NEW (Adam moments: zeros for added points, fdgs_trainer.py:354-355) get zeros in the
+ * rows r >= rows_carried.  row_bytes is any positive size; multiples of 4 with 4-byte aligned pointers move
+ * as words.                                                                                           */
+#define FDGS_SURGERY_MAX_ARRAYS 24
+#define FDGS_SURGERY_ZERO_NEW 1
+typedef struct {
+    int32_t rows_after;                /* counts[0] */
+    int32_t rows_carried;              /* counts[1] */
+    const int32_t* src;
+    int32_t num_arrays;
+    const void* in[FDGS_SURGERY_MAX_ARRAYS];
+    void* out[FDGS_SURGERY_MAX_ARRAYS];
+    int32_t row_bytes[FDGS_SURGERY_MAX_ARRAYS];
+    int32_t flags[FDGS_SURGERY_MAX_ARRAYS];
+} fdgs_surgery_apply_args;
+int fdgs_surgery_apply(const fdgs_surgery_apply_args* a, void* stream);
+
+/* Attributes of the split children (fdgs_trainer.py:402-407 with N = 2): for child j of 2 S (first children,
+ * then second children), parent i = src[first_child_row + j]:
+ *   xyz_out[row] = R(rotation[i]) (exp(scaling[i]) * noise[j]) + xyz[i],  scaling_out[row] = log(exp(scaling[i]) / 1.6)
+ * noise is N(0,1) drawn by the caller ([2 S,3]; torch.normal(mean=0, std) is std * N(0,1)).  xyz / scaling /
+ * rotation are the arrays BEFORE the surgery, xyz_out / scaling_out the ones after fdgs_surgery_apply. */
+typedef struct {
+    int32_t num_children;              /* 2 S */
+    int32_t first_child_row;           /* survivors + clones */
+    const int32_t* src;
+    const float* xyz; const float* scaling; const float* rotation;   /* old arrays */
+    const float* noise;                /* [2 S,3] */
+    float* xyz_out; float* scaling_out;                               /* new arrays */
+} fdgs_split_children_args;
+int fdgs_split_children(const fdgs_split_children_args* a, void* stream);
+
+/* Opacity reset (src/model/gaussian_model.py:173-176): logit <- inverse_sigmoid(min(sigmoid(logit), 0.01)),
+ * in place; the moments of the opacity tensor are zeroed by the caller (fdgs_trainer.py:304-317).     */
+int fdgs_reset_opacity(float* opacity, int32_t num_points, float cap, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
