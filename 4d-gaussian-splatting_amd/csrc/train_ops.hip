@@ -27,21 +27,31 @@ l1_partial_kernel(fdgs_l1_fwd_args a) {
     __shared__ float sh[4];
     const long long per_block = (long long)L1_THREADS * L1_PER_THREAD;
     const long long base = (long long)blockIdx.x * per_block;
-    float s = 0.0f;
+    float s = 0.0f, q = 0.0f;
     const bool vec = ((((size_t)a.a | (size_t)a.b) & 15) == 0) && base + per_block <= a.n;
     if (vec) {
 #pragma unroll
         for (int u = 0; u < L1_PER_THREAD / 4; ++u) {
             const long long i = base + 4 * (threadIdx.x + (long long)L1_THREADS * u);
             const float4 x = *reinterpret_cast<const float4*>(a.a + i), y = *reinterpret_cast<const float4*>(a.b + i);
-            s += (fabsf(x.x - y.x) + fabsf(x.y - y.y)) + (fabsf(x.z - y.z) + fabsf(x.w - y.w));
+            const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+            s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     } else {
-        for (long long i = base + threadIdx.x; i < base + per_block && i < a.n; i += L1_THREADS)
-            s += fabsf(a.a[i] - a.b[i]);
+        for (long long i = base + threadIdx.x; i < base + per_block && i < a.n; i += L1_THREADS) {
+            const float d = a.a[i] - a.b[i];
+            s += fabsf(d);
+            q += d * d;
+        }
     }
     s = block_sum_256(s, sh);
     if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
+    if (a.psnr) {                                  // uniform branch: the squared differences ride along
+        __syncthreads();
+        q = block_sum_256(q, sh);
+        if (threadIdx.x == 0) a.partial[gridDim.x + blockIdx.x] = q;
+    }
 }
 
 __global__ void __launch_bounds__(L1_THREADS)
@@ -56,6 +66,21 @@ l1_final_kernel(fdgs_l1_fwd_args a, int num_partials) {
         __syncthreads();
     }
     if (threadIdx.x == 0) a.loss[0] = (float)(shd[0] / (double)a.n * (double)a.scale);
+    if (a.psnr) {
+        __syncthreads();
+        double q = 0.0;
+        for (int i = threadIdx.x; i < num_partials; i += L1_THREADS) q += (double)a.partial[num_partials + i];
+        shd[threadIdx.x] = q;
+        __syncthreads();
+        for (int o = L1_THREADS / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float mse = (float)(shd[0] / (double)a.n);
+            a.psnr[0] = 20.0f * log10f(1.0f / sqrtf(mse));
+        }
+    }
 }
 
 extern "C" size_t fdgs_l1_loss_partials(int64_t n) {

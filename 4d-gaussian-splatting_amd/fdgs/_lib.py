@@ -102,7 +102,7 @@ class HexFeaturesArgs(C.Structure):
 
 
 class L1FwdArgs(C.Structure):
-    _fields_ = [("n", c_i64), ("a", c_p), ("b", c_p), ("scale", c_f), ("loss", c_p), ("partial", c_p)]
+    _fields_ = [("n", c_i64), ("a", c_p), ("b", c_p), ("scale", c_f), ("loss", c_p), ("partial", c_p), ("psnr", c_p)]
 
 
 class L1BwdArgs(C.Structure):
@@ -157,6 +157,21 @@ class SplitChildrenArgs(C.Structure):
                 ("xyz_out", c_p), ("scaling_out", c_p)]
 
 
+SSIM_MAX_RADIUS = 7
+
+
+class SsimFwdArgs(C.Structure):
+    _fields_ = [("planes", c_i32), ("height", c_i32), ("width", c_i32), ("img1", c_p), ("img2", c_p),
+                ("radius", c_i32), ("window", c_f * (2 * SSIM_MAX_RADIUS + 1)), ("c1", c_f), ("c2", c_f),
+                ("plane_sum", c_p), ("partial", c_p), ("dmaps", c_p)]
+
+
+class SsimBwdArgs(C.Structure):
+    _fields_ = [("planes", c_i32), ("height", c_i32), ("width", c_i32), ("img1", c_p), ("img2", c_p),
+                ("radius", c_i32), ("window", c_f * (2 * SSIM_MAX_RADIUS + 1)), ("dmaps", c_p),
+                ("plane_scale", c_p), ("grad_img1", c_p)]
+
+
 ADAM_MAX_TENSORS = 48
 
 
@@ -198,10 +213,13 @@ SYMBOLS = {
     "fdgs_surgery_apply": (C.c_int, [C.POINTER(SurgeryApplyArgs), c_p]),
     "fdgs_split_children": (C.c_int, [C.POINTER(SplitChildrenArgs), c_p]),
     "fdgs_reset_opacity": (C.c_int, [c_p, c_i32, c_f, c_p]),
+    "fdgs_ssim_tiles": (c_sz, [c_i32, c_i32]),
+    "fdgs_ssim_fwd": (C.c_int, [C.POINTER(SsimFwdArgs), c_p]),
+    "fdgs_ssim_bwd": (C.c_int, [C.POINTER(SsimBwdArgs), c_p]),
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 def _load():

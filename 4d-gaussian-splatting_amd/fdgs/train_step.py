@@ -25,8 +25,10 @@ class TrainStep:
     DYNERF_REGULATION = (0.001, 0.0001, 0.0002)
 
     def __init__(self, gaussians, deforms, background, lr_scale=1.0, stage="fine", fused_adam=True,
-                 regulation=DYNERF_REGULATION):
+                 regulation=DYNERF_REGULATION, lambda_dssim=0.0):
         self.g, self.deforms, self.bg, self.stage = gaussians, deforms, background, stage
+        self.lambda_dssim = float(lambda_dssim)     # configs/train/dynerf.yaml:36 ships 0
+        self.last_psnr = None                       # fdgs_trainer.py:131: mean PSNR of the local views, on device
         # fdgs_trainer.py:133-135: the grid regulariser joins the loss in the fine stage when its weight is set
         self.regulation = tuple(regulation) if (regulation and "fine" in stage and regulation[0] != 0) else None
         df = deforms.deformation_fields
@@ -106,16 +108,21 @@ class TrainStep:
         scale = dp.local_loss_scale(len(views), len(global_views))
         radii_list, vis_list, vsp_list = [], [], []
         loss = None
+        psnr_sum = None
         for cam in views:
             pkg = render(cam, self.g, self.deforms, self.bg, stage=self.stage, cam_type="dynerf")
-            if self.fused_tail:
-                l1 = losses.l1_loss(pkg["render"], cam.original_image, scale)
+            if self.fused_tail:     # loss and the iteration's PSNR (fdgs_trainer.py:130-131) from one pass
+                l1, view_psnr = losses.l1_loss_psnr(pkg["render"], cam.original_image, scale)
+                psnr_sum = view_psnr if psnr_sum is None else psnr_sum + view_psnr
             else:
                 l1 = torch.abs(pkg["render"] - cam.original_image).mean() * scale
             loss = l1 if loss is None else loss + l1
+            if self.lambda_dssim != 0:      # fdgs_trainer.py:136-138; the mean over the batch is the mean of the views'
+                loss = loss + (self.lambda_dssim * scale) * (1.0 - losses.ssim(pkg["render"], cam.original_image))
             radii_list.append(pkg["radii"])
             vis_list.append(pkg["visibility_filter"])
             vsp_list.append(pkg["viewspace_points"])
+        self.last_psnr = psnr_sum / len(views) if (psnr_sum is not None and len(views) > 1) else psnr_sum
         # fdgs_trainer.py:133-135.  A view-independent term: every rank takes 1/world of it and the gradient
         # all-reduce (a sum) completes it.
         reg = None

@@ -251,7 +251,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: DyNeRF-shaped synthetic scene, single-view training step "
-                                   "per GPU (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + L1 loss + grid regulariser + densification statistics + Adam)",
+                                   "per GPU (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + L1 loss and PSNR + grid regulariser + densification statistics + Adam)",
                        "gaussians": args.gaussians, "image": [args.width, args.height], "sh_degree": 3,
                        "global_batch_views": world, "views_per_gpu": 1, "visible_gaussians": visible,
                        "tile_list_entries": R,

@@ -302,7 +302,10 @@ typedef struct {
     const float* b;                  /* [n] ground truth                            */
     float scale;                     /* multiplies the mean (share of this view in a batch loss) */
     float* loss;                     /* [1]                                         */
-    float* partial;                  /* [fdgs_l1_loss_partials(n)] scratch          */
+    float* partial;                  /* [fdgs_l1_loss_partials(n)] scratch, twice that with psnr */
+    float* psnr;                     /* NULL, or [1]: 20 log10(1 / sqrt(mean (a-b)^2)) of the same n elements -
+                                        the per-iteration metric of src/model/metrics.py:7-28 (fdgs_trainer.py:131)
+                                        from the same pass over the two images */
 } fdgs_l1_fwd_args;
 typedef struct {
     int64_t n;
@@ -471,6 +474,36 @@ int fdgs_split_children(const fdgs_split_children_args* a, void* stream);
 /* Opacity reset (src/model/gaussian_model.py:173-176): logit <- inverse_sigmoid(min(sigmoid(logit), 0.01)),
  * in place; the moments of the opacity tensor are zeroed by the caller (fdgs_trainer.py:304-317).     */
 int fdgs_reset_opacity(float* opacity, int32_t num_points, float cap, void* stream);
+
+/* ---- SSIM (src/model/losses.py:13-53; joins the loss when lambda_dssim != 0, fdgs_trainer.py:136-138) ----
+ * planes = batch * channels images of height x width.  window: the 2 radius + 1 weights of the 1-D Gaussian
+ * (the reference's 2-D window is its outer product), zero padding.  plane_sum[p] = sum over the plane of
+ *   ((2 mu1 mu2 + c1)(2 s12 + c2)) / ((mu1^2 + mu2^2 + c1)(s1 + s2 + c2));
+ * the caller divides by the pixel count (mean over everything, or per image).  dmaps (optional) receives what
+ * the backward needs.  Backward: grad_img1 = plane_scale[p] * d plane_sum[p] / d img1.               */
+#define FDGS_SSIM_MAX_RADIUS 7
+typedef struct {
+    int32_t planes, height, width;
+    const float* img1; const float* img2;            /* [planes, height, width] */
+    int32_t radius;                                  /* window_size // 2, at most 7 */
+    float window[2 * FDGS_SSIM_MAX_RADIUS + 1];
+    float c1, c2;                                    /* 0.01^2, 0.03^2 */
+    float* plane_sum;                                /* [planes] out */
+    float* partial;                                  /* scratch, planes * fdgs_ssim_tiles(height, width) floats */
+    float* dmaps;                                    /* NULL, or [3, planes, height, width] out */
+} fdgs_ssim_fwd_args;
+typedef struct {
+    int32_t planes, height, width;
+    const float* img1; const float* img2;
+    int32_t radius;
+    float window[2 * FDGS_SSIM_MAX_RADIUS + 1];
+    const float* dmaps;                              /* written by the forward */
+    const float* plane_scale;                        /* [planes] */
+    float* grad_img1;                                /* [planes, height, width] out */
+} fdgs_ssim_bwd_args;
+size_t fdgs_ssim_tiles(int32_t height, int32_t width);
+int fdgs_ssim_fwd(const fdgs_ssim_fwd_args* a, void* stream);
+int fdgs_ssim_bwd(const fdgs_ssim_bwd_args* a, void* stream);
 
 #ifdef __cplusplus
 }
