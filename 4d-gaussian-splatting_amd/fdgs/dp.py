@@ -9,12 +9,18 @@ iteration: a single flat-bucket SUM all-reduce of every parameter gradient
 densification statistics the trainer keeps (fdgs_trainer.py:125-126,146-148):
 radii MAX, visibility MAX (= OR), summed view-space gradient SUM.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
+# FDGS_DP_SINGLE_RANK=1: take the exchange step even in a group of one rank (a rehearsal of the RCCL calls on a
+# one-GPU machine; the reductions are then identities)
+_SINGLE_RANK = os.environ.get("FDGS_DP_SINGLE_RANK") == "1"
+
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _SINGLE_RANK)
 
 
 def rank_world():

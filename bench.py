@@ -140,7 +140,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    grouped = world > 1 or os.environ.get("FDGS_DP_SINGLE_RANK") == "1"    # the latter: RCCL rehearsal on one GPU
+    if grouped:
         dist.init_process_group(backend="nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -158,7 +159,7 @@ def main():
         return [train_cams[(i * world + r) % len(train_cams)] for r in range(world)]
 
     def sync():
-        if world > 1:
+        if grouped:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -181,7 +182,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     prof, _lib.PROFILE = _lib.PROFILE, None
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -202,7 +203,7 @@ def main():
         sync()
         dt2 = time.perf_counter() - t2
         deformation.MATMUL = split_mode
-        if world > 1:
+        if grouped:
             t = torch.tensor([dt2], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt2 = float(t.item())
@@ -221,7 +222,7 @@ def main():
                 render(cams[20], g, deforms, bg)
             sync()
             dt = time.perf_counter() - t1
-        if world > 1:
+        if grouped:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -290,7 +291,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g, net, train_cams[0], bg)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -20,8 +20,13 @@ def main(out_dir):
     rank = int(os.environ.get("RANK", "0"))
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    if world > 1:
-        dist.init_process_group(backend="gloo")
+    # FDGS_TEST_BACKEND=nccl with FDGS_DP_SINGLE_RANK=1: the exchange step through RCCL in a group of one rank
+    backend = os.environ.get("FDGS_TEST_BACKEND", "gloo")
+    grouped = world > 1 or os.environ.get("FDGS_DP_SINGLE_RANK") == "1"
+    views_per_step = int(os.environ.get("FDGS_TEST_VIEWS", "2"))
+    tag = os.environ.get("FDGS_TEST_TAG", "")
+    if grouped:
+        dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
     torch.manual_seed(ss.SEED + rank)            # different RNG state per rank: TrainStep must equalise the replicas
     n, w, h = 6000, 160, 120
     g = ss.GaussianParams(n, device=dev, scale_mult=3.0)
@@ -42,13 +47,13 @@ def main(out_dir):
                                    for p in step.params]).cpu())
     step.optimizer.step = record
     for i in range(3):
-        step([cams[2 * i], cams[2 * i + 1]])
+        step([cams[2 * i + v] for v in range(views_per_step)])
     torch.cuda.synchronize()
     out = {f"grad{i}": t for i, t in enumerate(recorded)}
     out.update(accum=step.xyz_gradient_accum.cpu(), denom=step.denom.cpu(), maxr=step.max_radii2D.cpu(),
                w=net.deformation_net.pos_deform[1].weight.detach().cpu())
-    torch.save(out, os.path.join(out_dir, f"w{world}_r{rank}.pt"))
-    if world > 1:
+    torch.save(out, os.path.join(out_dir, f"w{world}_r{rank}{tag}.pt"))
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

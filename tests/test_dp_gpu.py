@@ -33,3 +33,28 @@ def test_two_ranks_match_one_rank(tmp_path):
         ref = one[k].float()
         assert float((a0[k].float() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12, k
     assert float(one["denom"].sum()) > 0 and torch.equal(a0["denom"], one["denom"]) and torch.equal(a0["maxr"], one["maxr"])
+
+
+def test_rccl_exchange_step_with_one_rank(tmp_path):
+    """The collectives of the exchange step through RCCL (backend "nccl") on the real device, in a group of one
+    rank (FDGS_DP_SINGLE_RANK=1; two ranks cannot share a GPU under RCCL): parameter broadcast, the early
+    asynchronous all-reduce of the SH gradient, the flat gradient bucket, the int32 MAX and float SUM of the
+    statistics.  Every reduction is then an identity, so gradients and statistics must equal the plain run's
+    (to rounding: the backward kernels accumulate with atomics, whose order differs from run to run)."""
+    worker = os.path.join(HERE, "dp_gpu_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FDGS_TEST_VIEWS="1")
+    r = subprocess.run([sys.executable, worker, str(tmp_path)], env=dict(env, FDGS_TEST_TAG="_plain"),
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29543", worker, str(tmp_path)]
+    r = subprocess.run(cmd, env=dict(env, FDGS_TEST_TAG="_rccl", FDGS_TEST_BACKEND="nccl", FDGS_DP_SINGLE_RANK="1"),
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    plain = torch.load(tmp_path / "w1_r0_plain.pt")
+    rccl = torch.load(tmp_path / "w1_r0_rccl.pt")
+    for k in plain:
+        ref = plain[k].float()
+        assert float((rccl[k].float() - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-12, k
+    assert float(plain["denom"].sum()) > 0 and torch.equal(plain["denom"], rccl["denom"])
+    assert torch.equal(plain["maxr"], rccl["maxr"]) and torch.equal(plain["w"], rccl["w"])
