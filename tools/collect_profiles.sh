@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the judged artifacts on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/prof/stats   rocprofv3 --kernel-trace --stats of `bench.py --steps 20`
+#   gpurun_out/prof/stats   rocprofv3 --kernel-trace --stats of `bench.py` (default steps and warm-up, as the plain bench line)
 #   gpurun_out/prof/fetch, gpurun_out/prof/write   one PMC pass each (FETCH_SIZE, WRITE_SIZE)
 #   gpurun_out/bench.json   the plain bench line (with the CPU baseline)
 # Every GPU step has its own time limit and the chain stops at the first failure.
@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT/prof
 cd /tmp && export TMPDIR=/tmp
-B="$ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --render-frames 0 --fp32-mfma-steps 0"
+B="$ROOT/bench.py --no-cpu-baseline --render-frames 0 --fp32-mfma-steps 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/prof/stats -o stats --output-format csv -- python3 $B > $OUT/prof/stats.log 2>&1
 echo "stats pass done"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/prof/fetch -o fetch --output-format csv -- python3 $B > $OUT/prof/fetch.log 2>&1
