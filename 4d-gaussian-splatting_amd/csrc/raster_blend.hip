@@ -244,8 +244,10 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
 
 extern "C" int fdgs_raster_blend_fwd(const fdgs_blend_fwd_args* a, void* stream) {
     if (!a || a->image_width <= 0 || a->image_height <= 0) return FDGS_EINVAL;
-    if (!a->ranges || !a->geom || !a->bg || !a->out_color || !a->out_depth || !a->final_T || !a->n_contrib)
-        return FDGS_EINVAL;   // point_list may be NULL when every range is empty
+    if (!a->ranges || !a->bg || !a->out_color || !a->out_depth || !a->final_T || !a->n_contrib)
+        return FDGS_EINVAL;
+    // point_list may be NULL when every range is empty, and then (a scene without Gaussians) so may geom
+    if (!a->geom && a->point_list) return FDGS_EINVAL;
     const int gx = fdgs_tiles_x(a->image_width), gy = fdgs_tiles_y(a->image_height);
     hipLaunchKernelGGL(blend_fwd_kernel, dim3(gx * gy), dim3(256), 0, (hipStream_t)stream, *a, gx);
     FDGS_CHECK_LAUNCH();
@@ -254,8 +256,8 @@ extern "C" int fdgs_raster_blend_fwd(const fdgs_blend_fwd_args* a, void* stream)
 
 extern "C" int fdgs_raster_blend_bwd(const fdgs_blend_bwd_args* a, void* stream) {
     if (!a || a->image_width <= 0 || a->image_height <= 0) return FDGS_EINVAL;
-    if (!a->ranges || !a->geom || !a->bg || !a->final_T || !a->n_contrib || !a->dL_dcolor || !a->dL_dgeom)
-        return FDGS_EINVAL;
+    if (!a->ranges || !a->bg || !a->final_T || !a->n_contrib || !a->dL_dcolor) return FDGS_EINVAL;
+    if ((!a->geom || !a->dL_dgeom) && a->point_list) return FDGS_EINVAL;   // both may be NULL with no Gaussians
     const int gx = fdgs_tiles_x(a->image_width), gy = fdgs_tiles_y(a->image_height);
     hipLaunchKernelGGL(blend_bwd_kernel, dim3(gx * gy), dim3(256), 0, (hipStream_t)stream, *a, gx);
     FDGS_CHECK_LAUNCH();

@@ -115,7 +115,8 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     if not keep_keys:
         st.keys_sorted = None
 
-    c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted), ptr(st.geom), ptr(bg), ptr(st.color),
+    # no list entries: the list pointer is NULL (the library then also accepts the NULL geom of an empty scene)
+    c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted) if R > 0 else None, ptr(st.geom), ptr(bg), ptr(st.color),
                           ptr(st.depth), ptr(st.final_T), ptr(st.n_contrib))
     _lib.call("fdgs_raster_blend_fwd", c)
     return st
@@ -129,7 +130,7 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, color
     vm, pm, cp, bg = st.cam
     dgeom = torch.zeros(N, _lib.GEOM_FLOATS, device=dev, dtype=torch.float32)
     gc = _f32c(grad_color)
-    a = _lib.BlendBwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted), ptr(st.geom), ptr(bg), ptr(st.final_T),
+    a = _lib.BlendBwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted) if st.num_rendered > 0 else None, ptr(st.geom), ptr(bg), ptr(st.final_T),
                           ptr(st.n_contrib), ptr(gc), ptr(dgeom))
     _lib.call("fdgs_raster_blend_bwd", a)
     d_means3D = torch.empty(N, 3, device=dev, dtype=torch.float32)

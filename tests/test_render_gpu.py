@@ -106,3 +106,33 @@ def test_activations_inside_the_rasterizer_match_torch():
         assert len(k[4]) == len(t[4])
         for a, b in zip(k[3] + k[4], t[3] + t[4]):
             assert float((a - b).abs().max() / (b.abs().max() + 1e-30)) <= 1e-4
+
+
+@pytest.mark.parametrize("n", [0, 1])
+def test_render_empty_and_single_gaussian_scene(n):
+    """A scene without Gaussians renders the background and back-propagates empty gradients (every tile range
+    empty, NULL list and geometry pointers at the C boundary); one Gaussian goes through every stage."""
+    from fdgs import scene_synth as ss
+    from fdgs.deformation import DeformationFields
+    from fdgs.renderer import render
+    from fdgs.train_step import DeformHolder
+    dev = torch.device("cuda:0")
+    g = ss.GaussianParams(1, device=dev)
+    if n == 0:
+        for a in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+            setattr(g, a, torch.nn.Parameter(getattr(g, a).detach()[:0].clone()))
+    torch.manual_seed(1)
+    net = ss.perturb_deformation_(DeformationFields(ss.DYNERF_NET_KWARGS)).to(dev)
+    net.deformation_net.set_aabb(list(ss.SCENE_MAX), list(ss.SCENE_MIN))
+    cam = ss.make_cameras(2, 160, 120, device=dev)[0]
+    bg = torch.tensor([1.0, 0.5, 0.25], device=dev)
+    for stage in ("coarse", "fine"):
+        pkg = render(cam, g, DeformHolder(net), bg, stage=stage)
+        (pkg["render"] - 0.5).abs().mean().backward()
+        torch.cuda.synchronize()
+        assert pkg["render"].shape == (3, 120, 160) and pkg["radii"].shape == (n,)
+        assert g._xyz.grad.shape == (n, 3) and pkg["viewspace_points"].grad.shape == (n, 3)
+        if n == 0:
+            assert torch.equal(pkg["render"], bg.view(3, 1, 1).expand(3, 120, 160))
+        else:
+            assert torch.isfinite(g._xyz.grad).all()
