@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from . import dp, losses
+from . import _lib, dp, losses
 from .renderer import render
 
 
@@ -42,8 +42,8 @@ class TrainStep:
             {"params": [gaussians._scaling], "lr": 0.005, "name": "scaling"},
             {"params": [gaussians._rotation], "lr": 0.001, "name": "rotation"},
         ]
-        on_gpu = gaussians._xyz.is_cuda
-        if fused_adam and on_gpu:       # one launch for all 40 tensors
+        _lib.require_gpu(gaussians._xyz)    # every kernel of the step lives in libfdgs.so: there is no CPU path
+        if fused_adam:                      # one launch for all 40 tensors
             from .adam import FusedAdam
             self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
         else:
@@ -56,7 +56,6 @@ class TrainStep:
         self.xyz_gradient_accum = torch.zeros(n, 1, device=dev)
         self.denom = torch.zeros(n, 1, device=dev)
         self.max_radii2D = torch.zeros(n, device=dev)
-        self.fused_tail = on_gpu            # L1 loss and densification statistics as single libfdgs passes
 
     def _bind_parameters(self):
         """The flat parameter list and the gradient buckets of the tensors the optimizer holds now."""
@@ -92,16 +91,6 @@ class TrainStep:
         self.surgery().reset_opacity()
         self._bind_parameters()
 
-    @torch.no_grad()
-    def _stats_torch(self, radii, vis, vgrad):
-        """fdgs_trainer.py:181-182 without boolean indexing (which would synchronise the host on the number
-        of visible points)."""
-        self.max_radii2D = torch.where(vis, torch.max(self.max_radii2D, radii.to(self.max_radii2D.dtype)),
-                                       self.max_radii2D)
-        visf = vis.unsqueeze(-1).to(self.denom.dtype)
-        self.xyz_gradient_accum += torch.norm(vgrad[:, :2], dim=-1, keepdim=True) * visf
-        self.denom += visf
-
     def __call__(self, global_views):
         """global_views: the whole batch (identical on every rank); returns the local loss value tensor."""
         views = dp.shard_views(global_views)
@@ -111,11 +100,9 @@ class TrainStep:
         psnr_sum = None
         for cam in views:
             pkg = render(cam, self.g, self.deforms, self.bg, stage=self.stage, cam_type="dynerf")
-            if self.fused_tail:     # loss and the iteration's PSNR (fdgs_trainer.py:130-131) from one pass
-                l1, view_psnr = losses.l1_loss_psnr(pkg["render"], cam.original_image, scale)
-                psnr_sum = view_psnr if psnr_sum is None else psnr_sum + view_psnr
-            else:
-                l1 = torch.abs(pkg["render"] - cam.original_image).mean() * scale
+            # loss and the iteration's PSNR (fdgs_trainer.py:130-131) from one pass over the two images
+            l1, view_psnr = losses.l1_loss_psnr(pkg["render"], cam.original_image, scale)
+            psnr_sum = view_psnr if psnr_sum is None else psnr_sum + view_psnr
             loss = l1 if loss is None else loss + l1
             if self.lambda_dssim != 0:      # fdgs_trainer.py:136-138; the mean over the batch is the mean of the views'
                 loss = loss + (self.lambda_dssim * scale) * (1.0 - losses.ssim(pkg["render"], cam.original_image))
@@ -130,8 +117,6 @@ class TrainStep:
         if self.regulation is not None:
             share = 1.0 / dp.rank_world()[1]
             reg_w = tuple(w * share for w in self.regulation)
-            if not self.fused_tail and loss is not None:
-                loss = loss + losses.compute_regulation(self.deforms.deformation_fields, *reg_w)
         early = []
         if loss is not None:
             from . import deformation
@@ -151,7 +136,7 @@ class TrainStep:
                 loss.backward()
             finally:
                 deformation.RESIDUAL_GRAD_HOOK = None
-        if reg_w is not None and self.fused_tail:
+        if reg_w is not None:
             # same gradients as adding the term to the loss, written into the planes' .grad in one launch
             reg = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
         n = self.g._xyz.shape[0]
@@ -174,10 +159,8 @@ class TrainStep:
             (self.bucket_without_sh if len(early) == 1 else self.bucket).allreduce_()
             radii, _, vgrad = dp.reduce_densification_stats(radii, None, vgrad)
             vis = radii > 0
-        if self.fused_tail:     # fdgs_trainer.py:181-182, gaussian_model.py:182-184 in one launch
-            losses.add_densification_stats(radii, vgrad, self.xyz_gradient_accum, self.denom, self.max_radii2D)
-        else:
-            self._stats_torch(radii, vis, vgrad)
+        # fdgs_trainer.py:181-182, gaussian_model.py:182-184 in one launch
+        losses.add_densification_stats(radii, vgrad, self.xyz_gradient_accum, self.denom, self.max_radii2D)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         out = loss.detach() if loss is not None else torch.zeros((), device=dev)
