@@ -275,7 +275,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dur * 1e3},
         }
         # the HBM-bound stages beside the north-star kernel: algorithmic bytes per call over the call's time
-        # (N Gaussians, V visible, P parameters; the figures are those of the kernel table in DESIGN.md)
+        # (N Gaussians, V visible, P parameters)
         N, V = float(args.gaussians), float(visible)
         n_param = float(sum(p.numel() for p in step.params))
         def hbm(name, nbytes):
