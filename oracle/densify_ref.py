@@ -12,10 +12,11 @@ path can be checked against the sequence it replaces:
   prune              src/runner/fdgs_trainer.py:477-484
   reset_opacity      src/model/gaussian_model.py:173-176  (replace_tensor_to_optimizer: fdgs_trainer.py:304-317)
 
-Parity unpinned: the reference has no test or fixture for this code and it cannot run here (it hard-codes
-device "cuda" and its module imports the absent rasterizer package); this file restates it from the source.
+Pinned by tests/golden/densify_small.npz: the outputs of the reference's own Gaussian4DTrainer._densify /
+_prune / _prune_points, run on the CPU by tests/golden/make_densify_golden.py (tests/test_oracle_densify.py).
 The random draw of the split (torch.normal(mean=0, std), fdgs_trainer.py:404) is std * N(0,1): the unit
-normal samples are an argument so that both sides of a parity test use the same ones.
+normal samples are an argument so that both sides of a parity test use the same ones.  reset_opacity has no
+reference output: the reference's method calls one that does not exist (gaussian_model.py:175).
 
 State: a dict with
   params  {name: [N, ...] float32}  names xyz, f_dc, f_rest, opacity, scaling, rotation

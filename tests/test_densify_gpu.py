@@ -303,3 +303,34 @@ def test_training_loop_with_surgery_converges():
     assert 0.3 < float(moved.max()) < 2.0
     print("loss %.4f -> %.4f, psnr %.2f -> %.2f, rows %s; after the reset %.4f -> %.4f" %
           (first, last, sum(psnrs[:6]) / 6, sum(psnrs[68:74]) / 6, rows, sum(losses[75:81]) / 6, sum(losses[84:90]) / 6))
+
+
+@pytest.mark.parametrize("tag", ["densify", "prune", "prune_no_size", "prune_points"])
+def test_against_reference_methods(tag):
+    """libfdgs surgery against tests/golden/densify_small.npz: the outputs of the reference's own
+    Gaussian4DTrainer._densify / _prune / _prune_points (run on the CPU by tests/golden/make_densify_golden.py)
+    for the same seeded state and the same unit normal samples."""
+    import test_oracle_densify as tod
+    from fdgs.densify import _ATTR
+    c = tod.GOLD_CASES[tag]
+    st = dc.make_state(c["n"], seed=c["seed"])
+    g, opt, d, surgery = _to_gpu(st, fused=(tag != "prune"))
+    children = 0
+    if tag == "densify":
+        noise = torch.from_numpy(tod.GOLD["densify_unit_noise"]).cuda()
+        out = surgery.densify(c["max_grad"], c["extent"], noise=noise)
+        children = 2 * out["splits"]
+        assert children == noise.shape[0]
+    elif tag == "prune_points":
+        out = surgery.prune_points((torch.arange(c["n"]) % 3 == 1).cuda())
+    else:
+        out = surgery.prune(c["min_opacity"], c["extent"], c["max_screen_size"])
+
+    def get(kind, name):
+        if kind == "param":
+            return getattr(g, _ATTR[name]).detach().cpu().numpy()
+        if kind == "stat":
+            holder = d if name.startswith("deformation") else g
+            return getattr(holder, name).cpu().numpy()
+        return opt.state[getattr(g, _ATTR[name])][kind].cpu().numpy()
+    tod.check_against_golden(tag, get, child_rows=out["rows"] - children if children else None, tol=CHILD_TOL)

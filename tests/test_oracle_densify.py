@@ -89,3 +89,60 @@ def test_prune_and_reset():
     assert o.max() <= 0.01 + 1e-6
     assert not st2["exp_avg"]["opacity"].any() and not st2["exp_avg_sq"]["opacity"].any()
     assert st2["exp_avg"]["xyz"].any()
+
+
+# ---- against the reference's own methods ---------------------------------------------------------------------
+# tests/golden/densify_small.npz holds what Gaussian4DTrainer._densify / _prune / _prune_points produced on the
+# CPU for the seeded states below (tests/golden/make_densify_golden.py); its cases are repeated here as data.
+import os
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "densify_small.npz"))
+GOLD_CASES = {"densify": dict(n=600, seed=101, max_grad=2e-4, extent=5.0),
+              "prune": dict(n=500, seed=102, min_opacity=0.2, extent=5.0, max_screen_size=20),
+              "prune_no_size": dict(n=500, seed=103, min_opacity=0.2, extent=5.0, max_screen_size=None),
+              "prune_points": dict(n=300, seed=104)}
+
+
+def run_oracle_case(tag):
+    c = GOLD_CASES[tag]
+    st = dc.make_state(c["n"], seed=c["seed"])
+    if tag == "densify":
+        noise = GOLD["densify_unit_noise"]
+        dr.densify(st, c["max_grad"], c["extent"], 0.01, lambda count: noise[:2 * count])
+    elif tag.startswith("prune_points"):
+        dr.prune_points(st, np.arange(c["n"]) % 3 == 1)
+    else:
+        dr.prune(st, c["min_opacity"], c["extent"], c["max_screen_size"])
+    return st
+
+
+def check_against_golden(tag, get, child_rows=None, tol=1e-6):
+    """get(kind, name) -> numpy array of the result; kind in {"param", "exp_avg", "exp_avg_sq", "stat"}."""
+    for k in dc.NAMES:
+        want = GOLD["%s_%s" % (tag, k)]
+        got = get("param", k)
+        assert got.shape == want.shape, (tag, k, got.shape, want.shape)
+        if child_rows is not None and k in ("xyz", "scaling"):
+            assert np.array_equal(got[:child_rows], want[:child_rows]), (tag, k)
+            err = np.abs(got[child_rows:] - want[child_rows:]).max()
+            assert err <= tol * max(np.abs(want[child_rows:]).max(), 1.0), (tag, k, err)
+        else:
+            assert np.array_equal(got, want), (tag, k)
+        for m in ("exp_avg", "exp_avg_sq"):
+            assert np.array_equal(get(m, k), GOLD["%s_%s_%s" % (tag, k, m)]), (tag, k, m)
+    for k in ("xyz_gradient_accum", "denom", "max_radii2D", "deformation_table", "deformation_accum"):
+        want = GOLD["%s_%s" % (tag, k)]
+        got = get("stat", k)
+        assert got.shape == want.shape and np.array_equal(got, want), (tag, k)
+
+
+def test_restatement_matches_reference_methods():
+    for tag in GOLD_CASES:
+        st = run_oracle_case(tag)
+        children = GOLD["densify_unit_noise"].shape[0] if tag == "densify" else 0
+
+        def get(kind, name):
+            return st["params"][name] if kind == "param" else (st[name] if kind == "stat" else st[kind][name])
+        rows = st["params"]["xyz"].shape[0]
+        check_against_golden(tag, get, child_rows=rows - children if children else None)
+    assert GOLD["densify_unit_noise"].shape[0] > 100 and GOLD["densify_xyz"].shape[0] > 700
