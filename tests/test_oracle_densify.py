@@ -1,7 +1,7 @@
 """CPU checks of oracle/densify_ref.py, the restatement of the reference's densification / pruning surgery
-(src/runner/fdgs_trainer.py:304-492).  The reference holds no fixture for this code and it cannot run here,
-so these are hand-derived cases: the row order the clone -> split -> prune sequence must produce, the
-optimizer moments of added rows, and the statistics reset."""
+(src/runner/fdgs_trainer.py:304-492): hand-derived cases (the row order the clone -> split -> prune sequence
+must produce, the optimizer moments of added rows, the statistics reset) and, at the end of the file, the outputs
+of the reference's own methods."""
 import numpy as np
 
 import densify_cases as dc
