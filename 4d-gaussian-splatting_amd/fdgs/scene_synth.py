@@ -56,11 +56,14 @@ class SynthCamera:
         self.image_width, self.image_height = int(width), int(height)
         self.time = float(time)
         self.znear, self.zfar = 0.01, 100.0
-        self.world_view_transform = torch.tensor(world_to_view(R, T)).transpose(0, 1).contiguous()
-        self.projection_matrix = perspective(self.znear, self.zfar, fovx, fovy).transpose(0, 1)
-        self.full_proj_transform = (self.world_view_transform.unsqueeze(0)
-                                    .bmm(self.projection_matrix.unsqueeze(0))).squeeze(0).contiguous()
-        self.camera_center = self.world_view_transform.inverse()[3, :3].contiguous()
+        # the same operations on the same (transposed, non-contiguous) views as src/scene/camera.py:48-53, so that
+        # the four tensors are bit-identical to the reference's; made contiguous afterwards
+        wvt = torch.tensor(world_to_view(R, T)).transpose(0, 1)
+        proj = perspective(self.znear, self.zfar, fovx, fovy).transpose(0, 1)
+        self.full_proj_transform = (wvt.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).contiguous()
+        self.camera_center = wvt.inverse()[3, :3].contiguous()
+        self.world_view_transform = wvt.contiguous()
+        self.projection_matrix = proj
         self.original_image = None
         self.to(device)
 

@@ -16,7 +16,10 @@ what the reference itself fixes:
   * SH basis and signs            src/utils/sh_utils.py:26-112 (+0.5 / clamp mirror at
                                   src/gaussian_renderer/__init__.py:95-96)
   * rotation / covariance         src/utils/general_utils.py:101-133 (Sigma = R S S^T R^T)
-It is therefore the normative oracle for this build: integer stages (radii,
+The last three - the parts whose arithmetic is in the reference's own files - are pinned by
+tests/golden/raster_parts.npz (outputs of the reference's Camera, eval_sh and GaussianModel.get_covariance,
+made by tests/golden/make_raster_parts_golden.py; checked in tests/test_oracle_raster_parts.py).  The stages
+after them are not.  It is therefore the normative oracle for this build: integer stages (radii,
 tile rectangles, keys, sort order, tile ranges) are compared bit for bit, the
 image within 1e-5 max-abs, gradients within 1e-4 relative.
 
@@ -100,6 +103,35 @@ def eval_sh_color(deg, sh, dx, dy, dz):
     return res
 
 
+def covariance3d(scales, rotations, scale_modifier=1.0):
+    """3-D covariance Sigma = (R S)(R S)^T as its six upper-triangle entries (xx, xy, xz, yy, yz, zz): what
+    GaussianModel.get_covariance builds (src/model/gaussian_model.py:43-50 with build_scaling_rotation and
+    strip_symmetric, src/utils/general_utils.py:86-133) for activated scales and a unit quaternion (r, x, y, z)."""
+    dt = scales.dtype
+    mod = torch.tensor(scale_modifier, dtype=dt)
+    sx, sy, sz = mod * scales[:, 0], mod * scales[:, 1], mod * scales[:, 2]
+    qr, qx, qy, qz = rotations[:, 0], rotations[:, 1], rotations[:, 2], rotations[:, 3]
+    R00 = 1.0 - 2.0 * (qy * qy + qz * qz)
+    R01 = 2.0 * (qx * qy - qr * qz)
+    R02 = 2.0 * (qx * qz + qr * qy)
+    R10 = 2.0 * (qx * qy + qr * qz)
+    R11 = 1.0 - 2.0 * (qx * qx + qz * qz)
+    R12 = 2.0 * (qy * qz - qr * qx)
+    R20 = 2.0 * (qx * qz - qr * qy)
+    R21 = 2.0 * (qy * qz + qr * qx)
+    R22 = 1.0 - 2.0 * (qx * qx + qy * qy)
+    M00, M01, M02 = R00 * sx, R01 * sy, R02 * sz
+    M10, M11, M12 = R10 * sx, R11 * sy, R12 * sz
+    M20, M21, M22 = R20 * sx, R21 * sy, R22 * sz
+    c00 = M00 * M00 + M01 * M01 + M02 * M02
+    c01 = M00 * M10 + M01 * M11 + M02 * M12
+    c02 = M00 * M20 + M01 * M21 + M02 * M22
+    c11 = M10 * M10 + M11 * M11 + M12 * M12
+    c12 = M10 * M20 + M11 * M21 + M12 * M22
+    c22 = M20 * M20 + M21 * M21 + M22 * M22
+    return c00, c01, c02, c11, c12, c22
+
+
 def preprocess(means3D, scales, rotations, opacities, shs, S, means2D=None, colors_precomp=None, cov3D_precomp=None):
     """Stage 1, per Gaussian.  scales are already exp-activated, rotations
     already normalised, opacities already sigmoid-activated
@@ -130,28 +162,7 @@ def preprocess(means3D, scales, rotations, opacities, shs, S, means2D=None, colo
     if cov3D_precomp is not None:      # src/gaussian_renderer/__init__.py:70-71 (compute_cov3D_python)
         c00, c01, c02, c11, c12, c22 = (cov3D_precomp[:, k] for k in range(6))
     else:
-        # 3-D covariance  Sigma = (R S)(R S)^T, R as src/utils/general_utils.py:108-121
-        mod = torch.tensor(S.scale_modifier, dtype=dt)
-        sx, sy, sz = mod * scales[:, 0], mod * scales[:, 1], mod * scales[:, 2]
-        qr, qx, qy, qz = rotations[:, 0], rotations[:, 1], rotations[:, 2], rotations[:, 3]
-        R00 = 1.0 - 2.0 * (qy * qy + qz * qz)
-        R01 = 2.0 * (qx * qy - qr * qz)
-        R02 = 2.0 * (qx * qz + qr * qy)
-        R10 = 2.0 * (qx * qy + qr * qz)
-        R11 = 1.0 - 2.0 * (qx * qx + qz * qz)
-        R12 = 2.0 * (qy * qz - qr * qx)
-        R20 = 2.0 * (qx * qz - qr * qy)
-        R21 = 2.0 * (qy * qz + qr * qx)
-        R22 = 1.0 - 2.0 * (qx * qx + qy * qy)
-        M00, M01, M02 = R00 * sx, R01 * sy, R02 * sz
-        M10, M11, M12 = R10 * sx, R11 * sy, R12 * sz
-        M20, M21, M22 = R20 * sx, R21 * sy, R22 * sz
-        c00 = M00 * M00 + M01 * M01 + M02 * M02
-        c01 = M00 * M10 + M01 * M11 + M02 * M12
-        c02 = M00 * M20 + M01 * M21 + M02 * M22
-        c11 = M10 * M10 + M11 * M11 + M12 * M12
-        c12 = M10 * M20 + M11 * M21 + M12 * M22
-        c22 = M20 * M20 + M21 * M21 + M22 * M22
+        c00, c01, c02, c11, c12, c22 = covariance3d(scales, rotations, S.scale_modifier)
 
     # EWA projection to a 2-D covariance
     tanx = torch.tensor(S.tanfovx, dtype=dt)
