@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from . import _lib, dp, losses
+from . import _lib, dp, losses, schedule
 from .renderer import render
 
 
@@ -48,6 +48,7 @@ class TrainStep:
             self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.learning_rates = schedule.LearningRates(spatial_lr_scale=lr_scale)   # fdgs_trainer.py:275-286
         self._bind_parameters()
         self.early_exchange = os.environ.get("FDGS_DP_EARLY", "1") != "0"
         dp.broadcast_parameters(self.params)      # replicas start identical whatever the ranks' RNG state was
@@ -91,8 +92,12 @@ class TrainStep:
         self.surgery().reset_opacity()
         self._bind_parameters()
 
-    def __call__(self, global_views):
-        """global_views: the whole batch (identical on every rank); returns the local loss value tensor."""
+    def __call__(self, global_views, iteration=None):
+        """global_views: the whole batch (identical on every rank); returns the local loss value tensor.
+        iteration: the trainer's counter; when given, the scheduled learning rates are set first
+        (fdgs_trainer.py:216, 288-302)."""
+        if iteration is not None:
+            self.learning_rates.update(self.optimizer, iteration)
         views = dp.shard_views(global_views)
         scale = dp.local_loss_scale(len(views), len(global_views))
         radii_list, vis_list, vsp_list = [], [], []

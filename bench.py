@@ -164,7 +164,7 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        step(batch(i))
+        step(batch(i), iteration=1 + i)
     sync()
     # a generation-2 collection of the cyclic garbage collector walks every live Python object (about 45 ms in a
     # process with torch loaded, more than ten training steps); the steps themselves create no cycles, so
@@ -177,7 +177,7 @@ def main():
     rendered = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(batch(args.warmup + i))
+        step(batch(args.warmup + i), iteration=1 + args.warmup + i)     # with the learning-rate schedule, as _run does
         rendered.append(rasterizer.LAST_NUM_RENDERED)
     sync()
     elapsed = time.perf_counter() - t0

@@ -138,3 +138,30 @@ def test_scene_files_round_trip(tmp_path):
     assert torch.equal(t2, table) and acc2.shape == (257, 3) and float(acc2.abs().sum()) == 0.0
     for (k, a), (_, b) in zip(net.state_dict().items(), net2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_schedules_match_reference_values():
+    """fdgs/schedule.py against tests/golden/schedule.json: learning rates written by the reference's own
+    Gaussian4DTrainer._update_learning_rate / get_expon_lr_func (tests/golden/make_schedule_golden.py)."""
+    import json
+    import torch
+    from fdgs import schedule
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "schedule.json")))
+    names = ["xyz", "deformation", "grid", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    groups = [{"params": [torch.nn.Parameter(torch.zeros(1))], "lr": 0.123, "name": n} for n in names]
+    opt = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+    lrs = schedule.LearningRates(spatial_lr_scale=gold["spatial_lr_scale"])
+    for it in gold["iters"]:
+        lrs.update(opt, it)
+        for g in opt.param_groups:
+            want = gold["lr"][str(it)][g["name"]]
+            assert abs(g["lr"] - want) <= 1e-15 + 4e-16 * abs(want) * 10, (it, g["name"], g["lr"], want)
+    f = schedule.get_expon_lr_func(lr_init=1e-2, lr_final=1e-4, lr_delay_steps=500, lr_delay_mult=0.05, max_steps=3000)
+    for it, want in gold["delayed"].items():
+        assert abs(f(int(it)) - want) <= 1e-14 * max(abs(want), 1e-3), (it, f(int(it)), want)
+    assert schedule.get_expon_lr_func(0.0, 0.0)(10) == gold["zero"] == 0.0
+    # fdgs_trainer.py:188-189 at both ends and in the middle
+    o, d = schedule.fine_thresholds(0, 10000, 0.005, 0.005, 0.0002, 0.0002)
+    assert (o, d) == (0.005, 0.0002)
+    o, d = schedule.fine_thresholds(5000, 10000, 0.01, 0.005, 0.0004, 0.0002)
+    assert abs(o - 0.0075) < 1e-15 and abs(d - 0.0003) < 1e-15
