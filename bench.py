@@ -242,10 +242,22 @@ def main():
         # HBM traffic per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
         # summarised by tools/pmc_summary.py into profiles/); only valid for the default workload
         traffic = None
+        valu_roofline = None
         if (args.gaussians, args.width, args.height) == (300000, 1352, 1014):
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
                 traffic = json.load(open(f)).get("blend_bwd_kernel", {}).get("traffic_bytes_per_launch")
+            # what actually bounds this kernel: vector-instruction issue.  Instructions per launch from the SQ
+            # counter pass of this same command (tools/sq_summary.py), over the launch time measured here, against
+            # 1024 SIMDs x one wave64 vector instruction per 4 cycles at 2.4 GHz
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")))[-1:]:
+                sq = json.load(open(f)).get("blend_bwd_kernel")
+                if sq and dur > 0:
+                    peak = sq["valu_issue_peak_ginst_per_s"]
+                    rate = sq["valu_insts_per_launch"] / dur / 1e9
+                    valu_roofline = {"kernel": "blend_bwd_kernel", "bound": "valu-issue", "achieved": rate,
+                                     "peak": peak, "unit": "G wave-instructions/s", "frac": rate / peak,
+                                     "valu_insts_per_launch": sq["valu_insts_per_launch"]}
         out = {
             "metric": "train it/s", "value": world * args.steps / elapsed, "unit": "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -273,6 +285,7 @@ def main():
             "roofline": {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dur * 1e3},
+            "roofline_valu": valu_roofline,
         }
         # the HBM-bound stages beside the north-star kernel: algorithmic bytes per call over the call's time
         # (N Gaussians, V visible, P parameters)
