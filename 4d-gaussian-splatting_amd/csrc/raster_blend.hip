@@ -5,11 +5,16 @@
 // on its own, with no workgroup barrier.  A batch of 64 list entries is loaded
 // one per lane; every lane tests whether its entry's 1/255-alpha ellipse can
 // reach the wave's quadrant, a 64-bit ballot collects the survivors and the wave
-// iterates over the set bits in list order, broadcasting the survivor's record
-// from its lane with v_readlane (scalar registers, no LDS).  Entries that cannot
-// reach the quadrant cost nothing; a quadrant stops as soon as its 64 pixels are
-// saturated.
+// iterates over the set bits in list order.  The survivor's record reaches all lanes
+// through a wave-private LDS copy of the batch (three 16-byte stores per lane per batch,
+// same-address reads per survivor, the next survivor's reads issued before the current
+// one is evaluated): both kernels are bound by vector-instruction issue, a v_readlane
+// per field is a vector instruction and an LDS read is not.  No workgroup barrier: a
+// wave's LDS instructions execute in program order.  Entries that cannot reach the
+// quadrant cost nothing; a quadrant stops as soon as its 64 pixels are saturated.
 #include "fdgs_common.h"
+
+#define BL_REC 2                                   // float4 per staged record: (x y A B) (C o r g); + one float2
 
 __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -47,6 +52,11 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
     const uint32_t r_begin = a.ranges[2 * tile], r_end = a.ranges[2 * tile + 1];
     const float4* __restrict__ geom4 = reinterpret_cast<const float4*>(a.geom);
 
+    __shared__ float4 staged[4][64 * BL_REC];
+    __shared__ float2 staged2[4][64];                       // forward: (b, depth)
+    float4* __restrict__ my = staged[wave];
+    float2* __restrict__ my2 = staged2[wave];
+
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
     uint32_t last = 0;
     bool done = !inside;
@@ -62,13 +72,27 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
             g1 = geom4[3 * (size_t)id + 1];
             g2 = geom4[3 * (size_t)id + 2];
         }
+        my[lane * BL_REC + 0] = g0;
+        my[lane * BL_REC + 1] = g1;
+        my2[lane] = make_float2(g2.x, g2.y);
         const bool hit = valid && splat_reaches(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, rx0, ry0, rx1, ry1);
         unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const float ex = bcast(g0.x, j), ey = bcast(g0.y, j);
-            const float A = bcast(g0.z, j), B = bcast(g0.w, j), C = bcast(g1.x, j), o = bcast(g1.y, j);
+        if (mask == 0ull) continue;
+        int jn = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        float4 n0 = my[jn * BL_REC + 0], n1 = my[jn * BL_REC + 1];
+        float2 n2 = my2[jn];
+        while (true) {
+            const float4 c0 = n0, c1 = n1;
+            const float2 c2 = n2;
+            const int j = jn;
+            const bool more = mask != 0ull;
+            if (more) {                                     // next survivor's record: in flight during this one
+                jn = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                n0 = my[jn * BL_REC + 0]; n1 = my[jn * BL_REC + 1]; n2 = my2[jn];
+            }
+            const float ex = c0.x, ey = c0.y, A = c0.z, B = c0.w, C = c1.x, o = c1.y;
             const float dx = ex - pxf, dy = ey - pyf;
             const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
             const float alpha = fminf(FDGS_ALPHA_MAX, o * __expf(power));
@@ -78,15 +102,15 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
                     done = true;
                 } else {
                     const float w = alpha * T;
-                    Cr += bcast(g1.z, j) * w;
-                    Cg += bcast(g1.w, j) * w;
-                    Cb += bcast(g2.x, j) * w;
-                    D += bcast(g2.y, j) * w;
+                    Cr += c1.z * w;
+                    Cg += c1.w * w;
+                    Cb += c2.x * w;
+                    D += c2.y * w;
                     T = test_T;
                     last = (base - r_begin) + (uint32_t)j + 1u;
                 }
             }
-            if (__ballot(!done) == 0ull) { mask = 0ull; }
+            if (!more || __ballot(!done) == 0ull) break;
         }
     }
     if (inside) {
@@ -170,74 +194,99 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d));
     wave_last = __builtin_amdgcn_readfirstlane(wave_last);
 
+    __shared__ float4 staged[4][64 * BL_REC];
+    __shared__ float2 staged2[4][64];                       // backward: (b, Gaussian index)
+    float4* __restrict__ my = staged[wave];
+    float2* __restrict__ my2 = staged2[wave];
+
     for (int hi = wave_last; hi > 0; hi -= 64) {
         const int pos = hi - 1 - lane;        // 0-based position in the tile list, back to front
         const bool valid = pos >= 0;
-        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-        uint32_t id = 0;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+        float2 g2 = make_float2(0.f, 0.f);
         if (valid) {
-            id = a.point_list[r_begin + (uint32_t)pos];
+            const uint32_t id = a.point_list[r_begin + (uint32_t)pos];
             g0 = geom4[3 * (size_t)id + 0];
             g1 = geom4[3 * (size_t)id + 1];
-            g2 = geom4[3 * (size_t)id + 2];
+            g2.x = a.geom[FDGS_GEOM_FLOATS * (size_t)id + 8];
+            g2.y = __uint_as_float(id);       // the Gaussian's index travels with the record
         }
+        my[lane * BL_REC + 0] = g0;
+        my[lane * BL_REC + 1] = g1;
+        my2[lane] = g2;
         const bool hit = valid && splat_reaches(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, rx0, ry0, rx1, ry1);
         unsigned long long mask = __ballot(hit);
-        while (mask) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
+        if (mask == 0ull) continue;
+        int jn = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        float4 n0 = my[jn * BL_REC + 0], n1 = my[jn * BL_REC + 1];
+        float2 n2 = my2[jn];
+        while (true) {
+            const float4 c0 = n0, c1 = n1;
+            const float2 c2 = n2;
+            const int j = jn;
+            const bool more = mask != 0ull;
+            if (more) {                                     // next survivor's record: in flight during this one
+                jn = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                n0 = my[jn * BL_REC + 0]; n1 = my[jn * BL_REC + 1]; n2 = my2[jn];
+            }
             const int p = hi - 1 - j;
-            const float ex = bcast(g0.x, j), ey = bcast(g0.y, j);
-            const float A = bcast(g0.z, j), B = bcast(g0.w, j), C = bcast(g1.x, j), o = bcast(g1.y, j);
+            const float ex = c0.x, ey = c0.y, A = c0.z, B = c0.w, C = c1.x, o = c1.y;
             const float dx = ex - pxf, dy = ey - pyf;
             const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
             const float G = __expf(power);
             const float alpha = fminf(FDGS_ALPHA_MAX, o * G);
             const bool contrib = (p < ncon) && power <= 0.0f && alpha >= FDGS_ALPHA_MIN;
-            if (__ballot(contrib) == 0ull) continue;
-
-            float v_mx = 0.f, v_my = 0.f, v_A = 0.f, v_B = 0.f, v_C = 0.f, v_o = 0.f, v_r = 0.f, v_g = 0.f, v_b = 0.f;
-            if (contrib) {
-                const float cr = bcast(g1.z, j), cg = bcast(g1.w, j), cb = bcast(g2.x, j);
-                const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - alpha);   // 1 ulp; alpha <= 0.99
+            if (__ballot(contrib) != 0ull) {
+                // No divergent branch: a lane that does not contribute runs the same arithmetic with alpha = 0 and
+                // G = 0, which leaves its state unchanged bit for bit (T * rcp(1) = T; the pending (last_alpha,
+                // last colour) pair is folded into acc now instead of at the next contributor - the same single
+                // expression on the same operands - and the pair it leaves, alpha 0, folds as 0 * c + 1 * acc = acc)
+                // and makes all nine of its partial sums exact zeros.
+                const float al = contrib ? alpha : 0.0f;
+                const float Ge = contrib ? G : 0.0f;
+                const float cr = c1.z, cg = c1.w, cb = c2.x;
+                const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - al);   // 1 ulp; alpha <= 0.99
                 T = T * inv_one_m;
-                const float w = alpha * T;
+                const float w = al * T;
                 acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r;
                 acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g;
                 acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b;
                 last_r = cr; last_g = cg; last_b = cb;
                 float dL_dalpha = (cr - acc_r) * dLr + (cg - acc_g) * dLg + (cb - acc_b) * dLb;
-                v_r = w * dLr; v_g = w * dLg; v_b = w * dLb;
+                const float v_r = w * dLr, v_g = w * dLg, v_b = w * dLb;
                 dL_dalpha *= T;
-                last_alpha = alpha;
+                last_alpha = al;
                 dL_dalpha += (-T_final * inv_one_m) * bg_dot;
                 const float dL_dG = o * dL_dalpha;
-                const float gdx = G * dx, gdy = G * dy;
-                v_mx = dL_dG * (-gdx * A - gdy * B);
-                v_my = dL_dG * (-gdy * C - gdx * B);
-                v_A = -0.5f * gdx * dx * dL_dG;
-                v_B = -gdx * dy * dL_dG;
-                v_C = -0.5f * gdy * dy * dL_dG;
-                v_o = G * dL_dalpha;
+                const float gdx = Ge * dx, gdy = Ge * dy;
+                const float v_mx = dL_dG * (-gdx * A - gdy * B);
+                const float v_my = dL_dG * (-gdy * C - gdx * B);
+                const float v_A = -0.5f * gdx * dx * dL_dG;
+                const float v_B = -gdx * dy * dL_dG;
+                const float v_C = -0.5f * gdy * dy * dL_dG;
+                const float v_o = Ge * dL_dalpha;
+                // Eight of the nine partial sums go through a transposing butterfly: each exchange step halves
+                // the number of live registers (v_permlane32_swap / v_permlane16_swap trade one register's upper
+                // half for another's lower half; row_ror:8 does the same inside a 16-lane row), so that the 8-lane
+                // group g = lane>>3 ends up owning the total of value g.  The ninth takes the plain DPP reduction.
+                float t0 = xswap32_add(v_mx, v_C), t1 = xswap32_add(v_my, v_o);   // lanes <32: v[i], >=32: v[i+4]
+                float t2 = xswap32_add(v_A, v_r), t3 = xswap32_add(v_B, v_g);
+                const float u0 = xswap16_add(t0, t2), u1 = xswap16_add(t1, t3);  // rows with bit4: v[i+2]
+                const float a8 = u0 + ror8(u0), b8 = u1 + ror8(u1);
+                float r = (lane & 8) ? b8 : a8;                                   // bit3: v[i+1]
+                r = dpp_add<0x111, 0xf>(r);                                       // sum of each 8-lane group ...
+                r = dpp_add<0x112, 0xf>(r);
+                r = dpp_add<0x114, 0xf>(r);                                       // ... lands in lanes 8g+7
+                const float s8 = wave_sum(v_b);
+                const uint32_t gid = __float_as_uint(c2.y);
+                if ((lane & 7) == 7 || lane == 0) {
+                    const int comp = lane == 0 ? 8 : (lane >> 3);
+                    atomicAdd(a.dL_dgeom + (size_t)gid * FDGS_GEOM_FLOATS + comp, lane == 0 ? s8 : r);
+                }
             }
-            // Eight of the nine partial sums go through a transposing butterfly: each exchange step halves
-            // the number of live registers (v_permlane32_swap / v_permlane16_swap trade one register's upper
-            // half for another's lower half; row_ror:8 does the same inside a 16-lane row), so that the 8-lane
-            // group g = lane>>3 ends up owning the total of value g.  The ninth takes the plain DPP reduction.
-            float t0 = xswap32_add(v_mx, v_C), t1 = xswap32_add(v_my, v_o);   // lanes <32: v[i], >=32: v[i+4]
-            float t2 = xswap32_add(v_A, v_r), t3 = xswap32_add(v_B, v_g);
-            const float u0 = xswap16_add(t0, t2), u1 = xswap16_add(t1, t3);  // rows with bit4: v[i+2]
-            const float a8 = u0 + ror8(u0), b8 = u1 + ror8(u1);
-            float r = (lane & 8) ? b8 : a8;                                   // bit3: v[i+1]
-            r = dpp_add<0x111, 0xf>(r);                                       // sum of each 8-lane group ...
-            r = dpp_add<0x112, 0xf>(r);
-            r = dpp_add<0x114, 0xf>(r);                                       // ... lands in lanes 8g+7
-            const float s8 = wave_sum(v_b);
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)id, j);
-            if ((lane & 7) == 7 || lane == 0) {
-                const int comp = lane == 0 ? 8 : (lane >> 3);
-                atomicAdd(a.dL_dgeom + (size_t)gid * FDGS_GEOM_FLOATS + comp, lane == 0 ? s8 : r);
-            }
+            if (!more) break;
         }
     }
 }
