@@ -7,8 +7,8 @@
 // reach the wave's quadrant, a 64-bit ballot collects the survivors and the wave
 // iterates over the set bits in list order.  The survivor's record reaches all lanes
 // through a wave-private LDS copy of the batch (three 16-byte stores per lane per batch,
-// same-address reads per survivor, the next survivor's reads issued before the current
-// one is evaluated): both kernels are bound by vector-instruction issue, a v_readlane
+// same-address reads per survivor; other waves of the SIMD cover the read's latency - issuing
+// the next survivor's reads ahead cost more in register copies than it hid): both kernels are bound by vector-instruction issue, a v_readlane
 // per field is a vector instruction and an LDS read is not.  No workgroup barrier: a
 // wave's LDS instructions execute in program order.  Entries that cannot reach the
 // quadrant cost nothing; a quadrant stops as soon as its 64 pixels are saturated.
@@ -78,20 +78,12 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
         const bool hit = valid && splat_reaches(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, rx0, ry0, rx1, ry1);
         unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
-        int jn = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        float4 n0 = my[jn * BL_REC + 0], n1 = my[jn * BL_REC + 1];
-        float2 n2 = my2[jn];
         while (true) {
-            const float4 c0 = n0, c1 = n1;
-            const float2 c2 = n2;
-            const int j = jn;
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
             const bool more = mask != 0ull;
-            if (more) {                                     // next survivor's record: in flight during this one
-                jn = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                n0 = my[jn * BL_REC + 0]; n1 = my[jn * BL_REC + 1]; n2 = my2[jn];
-            }
+            const float4 c0 = my[j * BL_REC + 0], c1 = my[j * BL_REC + 1];
+            const float2 c2 = my2[j];
             const float ex = c0.x, ey = c0.y, A = c0.z, B = c0.w, C = c1.x, o = c1.y;
             const float dx = ex - pxf, dy = ey - pyf;
             const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
@@ -217,20 +209,12 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
         const bool hit = valid && splat_reaches(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, rx0, ry0, rx1, ry1);
         unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
-        int jn = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        float4 n0 = my[jn * BL_REC + 0], n1 = my[jn * BL_REC + 1];
-        float2 n2 = my2[jn];
         while (true) {
-            const float4 c0 = n0, c1 = n1;
-            const float2 c2 = n2;
-            const int j = jn;
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1;
             const bool more = mask != 0ull;
-            if (more) {                                     // next survivor's record: in flight during this one
-                jn = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                n0 = my[jn * BL_REC + 0]; n1 = my[jn * BL_REC + 1]; n2 = my2[jn];
-            }
+            const float4 c0 = my[j * BL_REC + 0], c1 = my[j * BL_REC + 1];
+            const float2 c2 = my2[j];
             const int p = hi - 1 - j;
             const float ex = c0.x, ey = c0.y, A = c0.z, B = c0.w, C = c1.x, o = c1.y;
             const float dx = ex - pxf, dy = ey - pyf;
