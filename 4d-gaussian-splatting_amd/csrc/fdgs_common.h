@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <hip/hip_fp16.h>
 #include "fdgs.h"
 
 #define FDGS_WAVE 64
@@ -73,4 +74,48 @@ __device__ __forceinline__ void sh_tile_copy(float* __restrict__ tile, float* __
             *m = make_float4(t[0], t[1], t[2], t[3]);
         }
     }
+}
+
+// Slots 10 and 11 of the packed per-Gaussian record.
+//   [10]: radius in bits 0-27, SH clamp mask in bits 28-30.
+//   [11]: half-widths (x in the low, y in the high 16 bits, fp16 rounded up) of the axis-aligned box around the
+//         region where the splat's alpha can reach 1/255: the blend kernels' cull needs only four compares per list
+//         entry instead of a logarithm, a division and two square roots.  -inf: alpha never reaches 1/255
+//         anywhere; +inf: never skip.
+#define FDGS_RADIUS_MASK 0x0fffffff
+__device__ __forceinline__ int fdgs_pack_radius(int radius, int clampmask) {
+    return (radius & FDGS_RADIUS_MASK) | (clampmask << 28);
+}
+__device__ __forceinline__ int fdgs_unpack_radius(int bits) { return bits & FDGS_RADIUS_MASK; }
+__device__ __forceinline__ int fdgs_unpack_clampmask(int bits) { return (bits >> 28) & 7; }
+
+// alpha = o exp(power) >= 1/255  <=>  A dx^2 + 2 B dx dy + C dy^2 <= 2 ln(255 o); the box of that ellipse,
+// enlarged by a margin that covers float rounding in the per-pixel evaluation and the fp16 storage.
+__device__ __forceinline__ uint32_t fdgs_pack_reach(float A, float B, float C, float o) {
+    const float inf = __builtin_inff();
+    float hx, hy;
+    const float tau = __logf(255.0f * o);
+    if (!(tau >= 0.0f)) {                        // also o <= 0 and NaN
+        hx = hy = -inf;
+    } else {
+        const float s = 2.0f * tau * 1.001f + 0.001f;
+        const float det = A * C - B * B;
+        if (!(det > 0.0f)) {                     // degenerate conic: never skip
+            hx = hy = inf;
+        } else {
+            const float inv = s / det;
+            hx = sqrtf(inv * C) + 0.01f;
+            hy = sqrtf(inv * A) + 0.01f;
+            if (!(hx == hx)) hx = inf;
+            if (!(hy == hy)) hy = inf;
+        }
+    }
+    const uint32_t lo = __half_as_ushort(__float2half_ru(hx)), hi = __half_as_ushort(__float2half_ru(hy));
+    return lo | (hi << 16);
+}
+__device__ __forceinline__ bool fdgs_reaches(float gx, float gy, uint32_t reach, float rx0, float ry0, float rx1,
+                                             float ry1) {
+    const float hx = __half2float(__ushort_as_half((unsigned short)(reach & 0xffffu)));
+    const float hy = __half2float(__ushort_as_half((unsigned short)(reach >> 16)));
+    return (gx + hx >= rx0) && (gx - hx <= rx1) && (gy + hy >= ry0) && (gy - hy <= ry1);
 }

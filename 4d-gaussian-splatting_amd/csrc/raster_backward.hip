@@ -19,8 +19,8 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
     const float4* __restrict__ geom4 = reinterpret_cast<const float4*>(a.geom) + 3 * (size_t)i;
     const float4* __restrict__ dg4 = reinterpret_cast<const float4*>(a.dL_dgeom) + 3 * (size_t)i;
     const float4 g2 = geom4[2];
-    const int radius = __float_as_int(g2.z);
-    const int clampmask = __float_as_int(g2.w);
+    const int radius = fdgs_unpack_radius(__float_as_int(g2.z));
+    const int clampmask = fdgs_unpack_clampmask(__float_as_int(g2.z));
 
     float dmean[3] = {0.f, 0.f, 0.f}, dscale[3] = {0.f, 0.f, 0.f}, drot[4] = {0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dm2x = 0.f, dm2y = 0.f;

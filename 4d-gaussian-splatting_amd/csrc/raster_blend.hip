@@ -20,23 +20,6 @@ __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// Can the splat contribute alpha >= 1/255 anywhere in [rx0,rx1]x[ry0,ry1]?
-// alpha = o*exp(power) >= 1/255  <=>  A dx^2 + 2B dx dy + C dy^2 <= 2 ln(255 o).
-// The test uses the axis-aligned box of that ellipse, enlarged by a safety
-// margin that covers float rounding in the per-pixel evaluation.
-__device__ __forceinline__ bool splat_reaches(float gx, float gy, float A, float B, float C, float o, float rx0,
-                                              float ry0, float rx1, float ry1) {
-    const float tau = __logf(255.0f * o);
-    if (!(tau >= 0.0f)) return false;             // also rejects o <= 0 and NaN
-    const float s = 2.0f * tau * 1.001f + 0.001f;
-    const float det = A * C - B * B;
-    if (!(det > 0.0f)) return true;               // degenerate conic: never skip
-    const float inv = s / det;
-    const float hx = sqrtf(inv * C) + 0.01f;
-    const float hy = sqrtf(inv * A) + 0.01f;
-    return (gx + hx >= rx0) && (gx - hx <= rx1) && (gy + hy >= ry0) && (gy - hy <= ry1);
-}
-
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
     const int tile = blockIdx.x;
@@ -75,7 +58,7 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
         my[lane * BL_REC + 0] = g0;
         my[lane * BL_REC + 1] = g1;
         my2[lane] = make_float2(g2.x, g2.y);
-        const bool hit = valid && splat_reaches(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, rx0, ry0, rx1, ry1);
+        const bool hit = valid && fdgs_reaches(g0.x, g0.y, __float_as_uint(g2.w), rx0, ry0, rx1, ry1);
         unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
         while (true) {
@@ -196,17 +179,19 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
         const bool valid = pos >= 0;
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
         float2 g2 = make_float2(0.f, 0.f);
+        uint32_t reach = 0xfc00fc00u;         // (-inf, -inf): reaches nothing
         if (valid) {
             const uint32_t id = a.point_list[r_begin + (uint32_t)pos];
             g0 = geom4[3 * (size_t)id + 0];
             g1 = geom4[3 * (size_t)id + 1];
             g2.x = a.geom[FDGS_GEOM_FLOATS * (size_t)id + 8];
+            reach = __float_as_uint(a.geom[FDGS_GEOM_FLOATS * (size_t)id + 11]);
             g2.y = __uint_as_float(id);       // the Gaussian's index travels with the record
         }
         my[lane * BL_REC + 0] = g0;
         my[lane * BL_REC + 1] = g1;
         my2[lane] = g2;
-        const bool hit = valid && splat_reaches(g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, rx0, ry0, rx1, ry1);
+        const bool hit = valid && fdgs_reaches(g0.x, g0.y, reach, rx0, ry0, rx1, ry1);
         unsigned long long mask = __ballot(hit);
         if (mask == 0ull) continue;
         while (true) {

@@ -183,7 +183,8 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
     if (visible && (a.activations & FDGS_ACT_OPACITY_SIGMOID)) op = 1.0f / (1.0f + expf(-op));
     grec[0] = make_float4(px, py, conA, conB);
     grec[1] = make_float4(conC, op, cr, cg);
-    grec[2] = make_float4(cb, pvz, __int_as_float(radius), __int_as_float(clampmask));
+    grec[2] = make_float4(cb, pvz, __int_as_float(fdgs_pack_radius(radius, clampmask)),
+                          __uint_as_float(visible ? fdgs_pack_reach(conA, conB, conC, op) : 0xfc00fc00u));
     a.radii[i] = radius;
     a.tiles_touched[i] = touched;
 }
@@ -281,7 +282,7 @@ duplicate_with_keys_kernel(int n, const float* __restrict__ geom, const uint32_t
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 g2 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 2];
-    const int radius = __float_as_int(g2.z);
+    const int radius = fdgs_unpack_radius(__float_as_int(g2.z));
     if (radius <= 0) return;
     const float4 g0 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 0];
     uint32_t off = (i == 0) ? 0u : offsets[i - 1];

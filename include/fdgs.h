@@ -56,7 +56,10 @@ int fdgs_abi_version(void);
  * kernels (48 bytes, one or two cache lines per gather):
  *   [0] x_pix  [1] y_pix  [2] conic A  [3] conic B
  *   [4] conic C [5] opacity [6] r [7] g
- *   [8] b      [9] view depth [10] radius (int32 bits) [11] SH clamp mask (int32 bits, bit c = channel c clamped)
+ *   [8] b      [9] view depth
+ *   [10] int32 bits: radius in bits 0-27, SH clamp mask in bits 28-30 (bit 28 + c = channel c clamped)
+ *   [11] two fp16 (x low, y high): half-widths of the box in which the splat's alpha can reach 1/255 (the blend
+ *        kernels' per-entry cull), -inf = nowhere, +inf = never skip
  */
 
 /* Activations that the reference's render() applies between the deformation field and the rasterizer
