@@ -332,13 +332,15 @@ hexplane_features_split_kernel(HexFeatSK a) {
                 for (int ci = 0; ci < 6; ++ci) {
                     const int ax = plane_a(ci), bx = plane_b(ci);
                     const int Wd = h ? a.ps.res[1][ax] : a.ps.res[0][ax];
-                    const float* __restrict__ pl_ = (h ? a.ps.pl[1][ci] : a.ps.pl[0][ci]) + ch;
-                    const int o00 = axl[bx].i0 * Wd + axl[ax].i0;
-                    const int oy = axl[bx].d * Wd;
-                    tex[ci][0] = pl_[(size_t)o00 * DF];
-                    tex[ci][1] = pl_[(size_t)(o00 + axl[ax].d) * DF];
-                    tex[ci][2] = pl_[(size_t)(o00 + oy) * DF];
-                    tex[ci][3] = pl_[(size_t)(o00 + oy + axl[ax].d) * DF];
+                    // wave-uniform base + 32-bit lane offset (texel * DF + channel; a plane is far below 4 GB):
+                    // one address instruction per load instead of a 64-bit multiply-add
+                    const float* __restrict__ pl_ = h ? a.ps.pl[1][ci] : a.ps.pl[0][ci];
+                    const unsigned o00 = (unsigned)((axl[bx].i0 * Wd + axl[ax].i0) * DF + ch);
+                    const unsigned ox = (unsigned)(axl[ax].d * DF), oy = (unsigned)(axl[bx].d * Wd * DF);
+                    tex[ci][0] = pl_[o00];
+                    tex[ci][1] = pl_[o00 + ox];
+                    tex[ci][2] = pl_[o00 + oy];
+                    tex[ci][3] = pl_[o00 + oy + ox];
                 }
                 float feat = 1.0f;
 #pragma unroll
