@@ -6,15 +6,30 @@
 One "step" = one training iteration of the reference's loop body
 (src/runner/fdgs_trainer.py:112-205) on a synthetic DyNeRF-shaped scene: per
 view  deformation forward -> activations -> rasterizer forward -> L1 loss ->
-backward through both -> densification statistics -> Adam step.  At N GPUs the
-global batch is N views, one per rank (weak scaling), gradients and statistics
-are all-reduced over RCCL.  Rank 0 prints ONE JSON line.
+backward through both -> densification statistics -> Adam step.
+
+--gpus 1 (default): one view per iteration (the reference's batch_size 1,
+configs/train/dynerf.yaml:18).  --gpus N > 1: the global batch is a fixed 8
+views / time stamps per iteration (--global-batch), rank r renders views
+r, r+N, ... (8/N per rank: the reference's batch loop fdgs_trainer.py:239-248
+split over ranks), gradients and statistics are all-reduced over RCCL; `value`
+is then iterations of 8 views per second (strong scaling).  --global-batch 0
+means one view per rank (weak scaling).
+
+Run as `python bench.py --gpus N` without a launcher, this process touches no
+GPU: it starts `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a child, forwards rank 0's JSON line and exits with the child's status.
+Under a launcher (WORLD_SIZE set) it is one of the ranks.  Rank 0 prints ONE
+JSON line.
 """
 import argparse
 import gc
 import json
 import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -22,28 +37,110 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "4d-gaussian-splatting_amd"))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
+torch = None      # imported in main(), after the decision between launcher and rank
+dist = None
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=25,
                     help="untimed steps; the default walks all 20 training views once so that buffer sizes settle")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="views per iteration over all ranks (default: 1 at --gpus 1, 8 at --gpus > 1; 0 = one per rank)")
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--width", type=int, default=1352)
     ap.add_argument("--height", type=int, default=1014)
-    ap.add_argument("--render-frames", type=int, default=60, help="frames of the inference-only FPS leg (0 = skip)")
+    ap.add_argument("--render-frames", type=int, default=60, help="frames of the inference-only FPS legs (0 = skip)")
     ap.add_argument("--scale-mult", type=float, default=1.0, help="multiplier on the Gaussian scales (0.6 for the 2M case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fp32-mfma-steps", type=int, default=10,
                     help="steps of the extra leg that forms the deformation matrix products with fp32 MFMA (0 = skip)")
-    ap.add_argument("--cpu-tile-stride", type=int, default=48, help="cpu baseline blends every k-th tile")
-    return ap.parse_args()
+    ap.add_argument("--batch8-steps", type=int, default=6,
+                    help="at --gpus 1: steps of the extra leg with 8 views per iteration, the one-GPU point of the "
+                         "fixed-global-batch scaling curve (0 = skip)")
+    ap.add_argument("--cpu-tile-stride", type=int, default=48,
+                    help="cpu baseline blends every k-th tile, and every (k/2)-th for a second estimate")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="come up as ranks (gloo, no GPU, no kernels), prove the group and print the line's skeleton")
+    return ap.parse_args(argv)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# launcher: python bench.py --gpus N with no WORLD_SIZE in the environment
+# ----------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Starts N fresh rank processes (one per GPU) and forwards rank 0's JSON line.  Nothing here initialises
+    the GPU and nothing replaces this process: the ranks are children, their exit status is ours."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL needs dmabuf IPC on this driver
+    env.setdefault("OMP_NUM_THREADS", "16")
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)    # stderr passes through
+    line = None
+    for out in child.stdout:
+        text = out.strip()
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if rc != 0:
+        raise SystemExit(f"bench.py: the {args.gpus}-rank job failed with status {rc}")
+    if line is None:
+        raise SystemExit("bench.py: rank 0 printed no result line")
+    if json.loads(line).get("n_gpus") != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the result line reports {json.loads(line).get('n_gpus')}")
+    print(line, flush=True)
+
+
+def dry_run(args, world, rank):
+    """The group comes up over gloo on the CPU and every rank is counted; no kernel runs."""
+    import torch as t
+    import torch.distributed as d
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    d.init_process_group(backend="gloo", rank=rank, world_size=world)
+    seen = t.zeros(world, dtype=t.int64)
+    seen[rank] = 1 + rank
+    d.all_reduce(seen)
+    assert seen.tolist() == [1 + r for r in range(world)], seen
+    B = resolve_global_batch(args, world)
+    if rank == 0:
+        print(json.dumps({"metric": "train it/s", "value": None, "unit": "it/s", "n_gpus": world, "dry_run": True,
+                          "steps": args.steps, "warmup": args.warmup, "ranks_seen": int((seen > 0).sum()),
+                          "scaling": scaling_label(args, world),
+                          "config": {"global_batch_views": B, "views_per_gpu": B // world}}), flush=True)
+    d.barrier()
+    d.destroy_process_group()
+
+
+def resolve_global_batch(args, world):
+    B = args.global_batch
+    if B is None:
+        B = 1 if world == 1 else 8
+    if B == 0:
+        B = world
+    if B % world != 0:
+        raise SystemExit(f"--global-batch {B} does not divide over {world} ranks")
+    return B
+
+
+def scaling_label(args, world):
+    return "weak" if (world == 1 or args.global_batch == 0) else "strong"
+
+
+# ----------------------------------------------------------------------------------------------------------
 def build_scene(args, dev):
     from fdgs import scene_synth as ss
     from fdgs.deformation import DeformationFields
@@ -70,12 +167,39 @@ def build_scene(args, dev):
     return g, net, deforms, cams, bg
 
 
+def host_threads():
+    """Threads for the CPU baseline: the CPUs this process may actually use.  os.cpu_count() counts the whole
+    machine; the scheduler affinity and the OMP_NUM_THREADS the box exports (its per-GPU CPU share) bound it."""
+    total = os.cpu_count() or 1
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = total
+    env = os.environ.get("OMP_NUM_THREADS")
+    share = int(env) if env and env.isdigit() else None
+    threads = min(x for x in (total, affinity, share) if x)
+    return total, affinity, share, threads
+
+
+def _median_after_warmup(fn, repeats=3):
+    fn()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts)
+
+
 def cpu_baseline(args, g, net, cam, bg):
-    """The CPU oracle (oracle/deform_ref.py + oracle/raster_ref.py, torch CPU) on the same inputs:
-    deformation forward+backward on all points, rasterizer preprocess/sort on all points, blending
-    forward+backward on every k-th tile, extrapolated by the number of pixel-Gaussian pairs."""
+    """The CPU oracle (oracle/deform_ref.py + oracle/raster_ref.py, torch CPU) on the same inputs, each leg
+    timed as the median of 3 runs after one warm-up: deformation forward+backward and rasterizer
+    preprocess/sort + their backward on all points, blending forward+backward on every k-th tile, divided by
+    that sample's share of the tile-list entries - at two strides (k and k/2), so that the extrapolation's
+    stability shows."""
     from oracle import deform_ref, raster_ref as rr
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    total, affinity, share, threads = host_threads()
+    torch.set_num_threads(threads)
     cores = torch.get_num_threads()
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     for k in sd:
@@ -87,65 +211,118 @@ def cpu_baseline(args, g, net, cam, bg):
     S = rr.Settings(args.height, args.width, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), bg.cpu(), 1.0,
                     cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(), 3, cam.camera_center.cpu())
     gt = cam.original_image.cpu()
-    t0 = time.time()
-    pts, sc, ro, op, sh = deform_ref.deform_forward(sd, ins[0], ins[1], ins[2], ins[3], shs,
-                                                    torch.full((N, 1), float(cam.time)))
-    t_def_f = time.time() - t0
-    m2 = torch.zeros(N, 3, requires_grad=True)
-    t0 = time.time()
-    pre = rr.preprocess(pts, torch.exp(sc), torch.nn.functional.normalize(ro), torch.sigmoid(op), sh, S, m2)
-    keys, vals, _ = rr.build_keys(pre, S)
-    skeys, svals = rr.sort_keys(keys, vals)
+    tvec = torch.full((N, 1), float(cam.time))
     gx, gy = rr.tile_grid(S)
-    ranges = rr.tile_ranges(skeys, gx * gy)
-    t_pre = time.time() - t0
-    tiles = list(range(0, gx * gy, args.cpu_tile_stride))
-    lens = (ranges[:, 1] - ranges[:, 0]).to(torch.float64)
-    frac = float(lens[tiles].sum() / max(float(lens.sum()), 1.0))
-    t0 = time.time()
-    color, _, _, _ = rr.blend(pre, svals, ranges, S, tiles)
-    t_blend_f = time.time() - t0
-    mask = torch.zeros(gy * 16, gx * 16, dtype=torch.bool)
-    for t in tiles:
-        ty, tx = divmod(t, gx)
-        mask[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
-    mask = mask[:args.height, :args.width]
-    loss = (torch.abs(color - gt) * mask).sum() / (3.0 * args.height * args.width)
+    st = {}
+
+    def deform_fwd():
+        st["def"] = deform_ref.deform_forward(sd, ins[0], ins[1], ins[2], ins[3], shs, tvec)
+
+    def pre_sort():
+        pts, sc, ro, op, sh = st["def"]
+        st["m2"] = torch.zeros(N, 3, requires_grad=True)
+        pre = rr.preprocess(pts, torch.exp(sc), torch.nn.functional.normalize(ro), torch.sigmoid(op), sh, S, st["m2"])
+        keys, vals, _ = rr.build_keys(pre, S)
+        skeys, svals = rr.sort_keys(keys, vals)
+        st["pre"], st["svals"], st["ranges"] = pre, svals, rr.tile_ranges(skeys, gx * gy)
+
+    t_def_f = _median_after_warmup(deform_fwd)
+    t_pre = _median_after_warmup(pre_sort)
+    pre, svals, ranges = st["pre"], st["svals"], st["ranges"]
     mids = [pre[k] for k in ("px", "py", "conA", "conB", "conC", "opacity", "rgb")]
-    t0 = time.time()
-    gmid = torch.autograd.grad(loss, mids, retain_graph=True)     # blending backward, sampled tiles only
-    t_blend_b = time.time() - t0
-    t0 = time.time()
-    torch.autograd.backward(mids, gmid)                            # preprocess + deformation backward, all points
-    t_rest_b = time.time() - t0
-    t0 = time.time()                                               # grid regulariser of the fine stage, fwd + bwd
+    lens = (ranges[:, 1] - ranges[:, 0]).to(torch.float64)
+
+    def blend_legs(stride):
+        tiles = list(range(0, gx * gy, stride))
+        frac = float(lens[tiles].sum() / max(float(lens.sum()), 1.0))
+        mask = torch.zeros(gy * 16, gx * 16, dtype=torch.bool)
+        for t in tiles:
+            ty, tx = divmod(t, gx)
+            mask[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+        mask = mask[:args.height, :args.width]
+        box = {}
+
+        def fwd():
+            color, _, _, _ = rr.blend(pre, svals, ranges, S, tiles)
+            box["loss"] = (torch.abs(color - gt) * mask).sum() / (3.0 * args.height * args.width)
+
+        def bwd():
+            box["gmid"] = torch.autograd.grad(box["loss"], mids, retain_graph=True)
+
+        tf = _median_after_warmup(fwd)
+        tb = _median_after_warmup(bwd)
+        return {"stride": stride, "tiles": len(tiles), "entry_fraction": frac, "fwd_s": tf, "bwd_s": tb,
+                "extrapolated_s": (tf + tb) / max(frac, 1e-9)}, box["gmid"]
+
+    b1, gmid = blend_legs(args.cpu_tile_stride)
+    b2, _ = blend_legs(max(1, args.cpu_tile_stride // 2))
+    leaves = ins + [shs] + [v for v in sd.values() if v.requires_grad]
+
+    def rest_bwd():     # preprocess + activations + deformation backward, all points
+        for t in leaves:
+            t.grad = None
+        torch.autograd.backward(mids, gmid, retain_graph=True)
+
+    t_rest_b = _median_after_warmup(rest_bwd)
     from fdgs.train_step import TrainStep
-    deform_ref.compute_regulation(sd, *TrainStep.DYNERF_REGULATION).backward()
-    t_reg = time.time() - t0
-    est = t_def_f + t_pre + (t_blend_f + t_blend_b) / max(frac, 1e-9) + t_rest_b + t_reg
-    measured = t_def_f + t_pre + t_blend_f + t_blend_b + t_rest_b + t_reg
-    return {"value": 1.0 / est, "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": (f"deformation fwd+bwd, grid regulariser and rasterizer preprocess/sort on all {N} points; blending fwd+bwd on "
-                       f"every {args.cpu_tile_stride}th tile ({len(tiles)} of {gx * gy} tiles, {frac:.4f} of the "
-                       f"tile-list entries), blending time divided by that fraction; measured {measured:.1f} s"),
-            "seconds_measured": measured, "estimated_step_seconds": est}
+
+    def reg():          # grid regulariser of the fine stage, fwd + bwd
+        deform_ref.compute_regulation(sd, *TrainStep.DYNERF_REGULATION).backward()
+
+    t_reg = _median_after_warmup(reg)
+    blend_s = 0.5 * (b1["extrapolated_s"] + b2["extrapolated_s"])
+    est = t_def_f + t_pre + blend_s + t_rest_b + t_reg
+    return {"value": 1.0 / est, "unit": "it/s", "cores": cores, "threads": cores, "cpu_count": total,
+            "cpu_affinity": affinity, "omp_num_threads_env": share, "kind": "port",
+            "sample": (f"median of 3 after 1 warm-up per leg on {cores} threads (machine: {total} CPUs, this process may "
+                       f"use {affinity}, the box's per-GPU share OMP_NUM_THREADS={share}); deformation fwd+bwd, grid "
+                       f"regulariser and rasterizer preprocess/sort on all {N} points; blending fwd+bwd on every "
+                       f"{b1['stride']}th tile ({b1['tiles']} of {gx * gy} tiles, {b1['entry_fraction']:.4f} of the "
+                       f"tile-list entries) and on every {b2['stride']}th ({b2['tiles']} tiles, {b2['entry_fraction']:.4f}), "
+                       f"each divided by its fraction: {b1['extrapolated_s']:.2f} s and {b2['extrapolated_s']:.2f} s, mean used"),
+            "legs_s": {"deform_fwd": t_def_f, "preprocess_sort": t_pre, "blend_fwd_bwd_extrapolated": blend_s,
+                       "preprocess_deform_bwd": t_rest_b, "regulariser": t_reg},
+            "blend_estimates": [b1, b2],
+            "blend_estimates_rel_diff": abs(b1["extrapolated_s"] - b2["extrapolated_s"]) / max(blend_s, 1e-9),
+            "estimated_step_seconds": est}
 
 
 def main():
-    args = parse()
+    global torch, dist
+    argv = sys.argv[1:]
+    args = parse(argv)
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        return launch_ranks(args, argv)       # before anything touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        return dry_run(args, world, rank)
+    import torch as _torch
+    import torch.distributed as _dist
+    torch, dist = _torch, _dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # FDGS_BENCH_SHARE_GPU=1: rehearsal of the N-rank job on a one-GPU machine - every rank on cuda:0, collectives
+    # over gloo staged through host memory (two RCCL ranks cannot share a device).  Not a measurement.
+    share_gpu = os.environ.get("FDGS_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     grouped = world > 1 or os.environ.get("FDGS_DP_SINGLE_RANK") == "1"    # the latter: RCCL rehearsal on one GPU
     if grouped:
-        dist.init_process_group(backend="nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if share_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
 
-    from fdgs import _lib, rasterizer
+    from fdgs import _lib, dp, rasterizer
     from fdgs.renderer import render
     from fdgs.train_step import TrainStep
 
@@ -154,14 +331,25 @@ def main():
     g, net, deforms, cams, bg = build_scene(args, dev)
     step = TrainStep(g, deforms, bg)
     train_cams = cams[:20]
+    B = resolve_global_batch(args, world)
+    per_rank = B // world
 
-    def batch(i):
-        return [train_cams[(i * world + r) % len(train_cams)] for r in range(world)]
+    def batch(i, size=B):
+        """The whole batch of iteration i, the same list on every rank (TrainStep shards it): `size` views, each
+        with its own camera and time stamp (SynthCamera.time), walking the 20 training views."""
+        return [train_cams[(i * size + j) % len(train_cams)] for j in range(size)]
 
     def sync():
         if grouped:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if not grouped:
+            return seconds
+        t = torch.tensor([seconds], device=dev, dtype=torch.float64)
+        dp.all_reduce_(t, dist.ReduceOp.MAX)
+        return float(t.item())
 
     for i in range(args.warmup):
         step(batch(i), iteration=1 + i)
@@ -173,6 +361,7 @@ def main():
     gc.freeze()
     with torch.no_grad():       # visible Gaussians of the first training view (recorded, not timed)
         visible = int((render(train_cams[rank % len(train_cams)], g, deforms, bg)["radii"] > 0).sum())
+    sync()
     _lib.PROFILE = {}
     rendered = []
     t0 = time.perf_counter()
@@ -180,12 +369,8 @@ def main():
         step(batch(args.warmup + i), iteration=1 + args.warmup + i)     # with the learning-rate schedule, as _run does
         rendered.append(rasterizer.LAST_NUM_RENDERED)
     sync()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     prof, _lib.PROFILE = _lib.PROFILE, None
-    if grouped:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     # extra leg, not the headline: same step with the deformation matrix products on v_mfma_f32_32x32x2_f32
     # instead of the exact three-way bf16 split (both take, accumulate and return fp32)
@@ -201,17 +386,26 @@ def main():
         for i in range(args.fp32_mfma_steps):
             step(batch(2 + i))
         sync()
-        dt2 = time.perf_counter() - t2
+        dt2 = max_over_ranks(time.perf_counter() - t2)
         deformation.MATMUL = split_mode
-        if grouped:
-            t = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
-        fp32_mfma = world * args.fp32_mfma_steps / dt2
+        fp32_mfma = args.fp32_mfma_steps / dt2
 
-    # inference-only leg: deformation + forward rasterizer, frames strided over ranks, no collective
-    fps = None
+    # extra leg at one GPU: 8 views per iteration, the N = 1 point of the fixed-global-batch scaling curve
+    batch8 = None
+    if world == 1 and B == 1 and args.batch8_steps > 0:
+        for i in range(2):
+            step(batch(i, 8))
+        sync()
+        t3 = time.perf_counter()
+        for i in range(args.batch8_steps):
+            step(batch(2 + i, 8))
+        sync()
+        batch8 = args.batch8_steps / (time.perf_counter() - t3)
+
+    # inference-only legs: deformation + forward rasterizer, frames strided over ranks, no collective
+    fps = fps_d2h = None
     if args.render_frames > 0:
+        import numpy as np
         frames = list(range(rank, args.render_frames, world))
         with torch.no_grad():
             render(cams[20], g, deforms, bg)
@@ -221,12 +415,20 @@ def main():
                 cams[20].time = f / 300.0
                 render(cams[20], g, deforms, bg)
             sync()
-            dt = time.perf_counter() - t1
-        if grouped:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        fps = args.render_frames / dt
+            fps = args.render_frames / max_over_ranks(time.perf_counter() - t1)
+            # the reference's own FPS figure (render.py:74-89) includes, per frame, the copy of the float image
+            # to the host and its 8-bit conversion there (render.py:47,78)
+            def to8b(x):
+                return (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8)
+            images = [to8b(render(cams[20], g, deforms, bg)["render"]).transpose(1, 2, 0)]
+            sync()
+            t1 = time.perf_counter()
+            for f in frames:
+                cams[20].time = f / 300.0
+                images.append(to8b(render(cams[20], g, deforms, bg)["render"]).transpose(1, 2, 0))
+            sync()
+            fps_d2h = args.render_frames / max_over_ranks(time.perf_counter() - t1)
+            del images
 
     if rank == 0:
         def avg_ms(name):
@@ -247,9 +449,8 @@ def main():
             import glob
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1:]:
                 traffic = json.load(open(f)).get("blend_bwd_kernel", {}).get("traffic_bytes_per_launch")
-            # what actually bounds this kernel: vector-instruction issue.  Instructions per launch from the SQ
-            # counter pass of this same command (tools/sq_summary.py), over the launch time measured here, against
-            # 1024 SIMDs x one wave64 vector instruction per 4 cycles at 2.4 GHz
+            # vector-instruction issue: instructions per launch from the SQ counter pass of this same command
+            # (tools/sq_summary.py), over the launch time measured here
             for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq.json")))[-1:]:
                 sq = json.load(open(f)).get("blend_bwd_kernel")
                 if sq and dur > 0:
@@ -257,40 +458,60 @@ def main():
                     rate = sq["valu_insts_per_launch"] / dur / 1e9
                     valu_roofline = {"kernel": "blend_bwd_kernel", "bound": "valu-issue", "achieved": rate,
                                      "peak": peak, "unit": "G wave-instructions/s", "frac": rate / peak,
-                                     "valu_insts_per_launch": sq["valu_insts_per_launch"]}
+                                     "valu_insts_per_launch": sq["valu_insts_per_launch"],
+                                     "counters_from": os.path.basename(f)}
+        mlp_s = (avg_ms("fdgs_deform_fwd") + avg_ms("fdgs_deform_bwd")) * 1e-3 or 1.0
+        mlp_flop = 3 * 187136.0 * args.gaussians          # fp32 semantics, forward + backward, per view
         out = {
-            "metric": "train it/s", "value": world * args.steps / elapsed, "unit": "it/s",
+            "metric": "train it/s", "value": args.steps / elapsed, "unit": "it/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": scaling_label(args, world),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: DyNeRF-shaped synthetic scene, single-view training step "
-                                   "per GPU (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + L1 loss and PSNR + grid regulariser + densification statistics + Adam)",
+            "config": {"workload": ("BASELINE configs[1]: DyNeRF-shaped synthetic scene, single-view training step"
+                                    if B == 1 else
+                                    f"BASELINE configs[2]: DyNeRF-shaped synthetic scene, {B} views / time stamps per "
+                                    f"iteration split over {world} GPU(s), RCCL gradient all-reduce")
+                                   + " (fine stage: HexPlane deformation + tile rasterizer fwd+bwd + L1 loss and PSNR"
+                                     " + grid regulariser + densification statistics + Adam)",
                        "gaussians": args.gaussians, "image": [args.width, args.height], "sh_degree": 3,
-                       "global_batch_views": world, "views_per_gpu": 1, "visible_gaussians": visible,
+                       "global_batch_views": B, "views_per_gpu": per_rank, "visible_gaussians": visible,
                        "tile_list_entries": R,
                        "parallelism": f"dp{world}",
                        "deform_matmul": ("fp32 in / fp32 accumulate / fp32 out; products formed from an exact "
                                          "three-way bf16 split of both operands, six bf16 MFMA terms (error below "
                                          "one fp32 rounding per product)" if split_is_default else "fp32 MFMA")},
+            "views_per_s": B * args.steps / elapsed,
             "train_it_s_fp32_mfma": fp32_mfma,
+            "train_it_s_global_batch_8": batch8,
             "render_fps": fps,
+            "render_fps_with_d2h": fps_d2h,
             "kernel_ms": per_call,
-            # deformation MLP, forward + backward: 3 x 187,136 flop per point (fp32 semantics) over the two calls,
-            # against the dense fp32 matrix-core peak (157.3 TFLOP/s); the calls include the HexPlane gather/scatter
-            "roofline_deform_mlp": (lambda t: {"bound": "mfma", "achieved": 3 * 187136.0 * args.gaussians / t / 1e12,
-                                               "peak": 157.3, "unit": "TFLOP/s (fp32-equivalent)",
-                                               "frac": 3 * 187136.0 * args.gaussians / t / 1e12 / 157.3,
-                                               "calls": "fdgs_deform_fwd + fdgs_deform_bwd"})(
-                (avg_ms("fdgs_deform_fwd") + avg_ms("fdgs_deform_bwd")) * 1e-3 or 1.0),
+            # deformation MLP, forward + backward: 3 x 187,136 flop per point in fp32 semantics.  The split mode
+            # issues six bf16 MFMA terms per product: issued bf16 flop = 6 x that, against the dense bf16 peak;
+            # the fp32-equivalent figure against the fp32 matrix-core peak is kept beside it.  The two calls
+            # include the HexPlane gather / scatter.
+            "roofline_deform_mlp": {"bound": "mfma",
+                                    "achieved": (6 if split_is_default else 1) * mlp_flop / mlp_s / 1e12,
+                                    "peak": 2500.0 if split_is_default else 157.3,
+                                    "unit": "TFLOP/s issued (bf16 terms)" if split_is_default else "TFLOP/s (fp32 MFMA)",
+                                    "frac": ((6 * mlp_flop / mlp_s / 1e12 / 2500.0) if split_is_default
+                                             else mlp_flop / mlp_s / 1e12 / 157.3),
+                                    "fp32_equivalent_tflops": mlp_flop / mlp_s / 1e12,
+                                    "fp32_equivalent_frac_of_157.3": mlp_flop / mlp_s / 1e12 / 157.3,
+                                    "calls": "fdgs_deform_fwd + fdgs_deform_bwd"},
             "roofline": {"kernel": "blend_bwd_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dur * 1e3},
             "roofline_valu": valu_roofline,
         }
+        if share_gpu:
+            out["rehearsal"] = "all ranks on one GPU over gloo: not a measurement"
         # the HBM-bound stages beside the north-star kernel: algorithmic bytes per call over the call's time
         # (N Gaussians, V visible, P parameters)
         N, V = float(args.gaussians), float(visible)
         n_param = float(sum(p.numel() for p in step.params))
+
         def hbm(name, nbytes):
             t = avg_ms(name) * 1e-3
             return {"call": name, "bound": "hbm", "achieved": nbytes / t / 1e9 if t > 0 else 0.0, "peak": 8000.0,
@@ -300,6 +521,7 @@ def main():
             hbm("fdgs_adam_step", 28.0 * n_param),
             hbm("fdgs_l1_loss_bwd", 12.0 * 3 * px),
             hbm("fdgs_raster_blend_fwd", 44.0 * R + 28.0 * px),
+            hbm("fdgs_raster_bin_sort", 24.0 * V + 12.0 * R + 24.0 * R + 8.0 * R),
         ]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g, net, train_cams[0], bg)
