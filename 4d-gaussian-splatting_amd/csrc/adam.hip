@@ -7,8 +7,8 @@
 struct AdamK {
     fdgs_adam_args a;
     int block_start[FDGS_ADAM_MAX_TENSORS + 1];
-    float step_size[FDGS_ADAM_MAX_TENSORS];      // lr / (1 - beta1^t)
-    float inv_sqrt_bc2;                          // 1 / sqrt(1 - beta2^t)
+    float step_size[FDGS_ADAM_MAX_TENSORS];      // lr / (1 - beta1^t), t = the tensor's own step count
+    float inv_sqrt_bc2[FDGS_ADAM_MAX_TENSORS];   // 1 / sqrt(1 - beta2^t)
     float omb1, omb2;                            // 1 - beta, formed in double as the reference's Python does
 };
 
@@ -33,7 +33,7 @@ adam_kernel(AdamK k) {
     float* __restrict__ m = k.a.exp_avg[t];
     float* __restrict__ v = k.a.exp_avg_sq[t];
     const long long n = k.a.numel[t];
-    const float o1 = k.omb1, b2 = (float)k.a.beta2, o2 = k.omb2, eps = (float)k.a.eps, ss = k.step_size[t], ib = k.inv_sqrt_bc2;
+    const float o1 = k.omb1, b2 = (float)k.a.beta2, o2 = k.omb2, eps = (float)k.a.eps, ss = k.step_size[t], ib = k.inv_sqrt_bc2[t];
     const long long base = (long long)((int)blockIdx.x - k.block_start[t]) * ADAM_PER_BLOCK;
     const bool vec = ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0);
     if (vec && base + ADAM_PER_BLOCK <= n) {
@@ -61,21 +61,22 @@ adam_kernel(AdamK k) {
 }
 
 extern "C" int fdgs_adam_step(const fdgs_adam_args* a, void* stream) {
-    if (!a || a->num_tensors < 0 || a->num_tensors > FDGS_ADAM_MAX_TENSORS || a->step < 1) return FDGS_EINVAL;
+    if (!a || a->num_tensors < 0 || a->num_tensors > FDGS_ADAM_MAX_TENSORS) return FDGS_EINVAL;
     if (!(a->beta1 >= 0.0 && a->beta1 < 1.0 && a->beta2 >= 0.0 && a->beta2 < 1.0)) return FDGS_EINVAL;
     AdamK k;
     k.a = *a;
-    const double bc1 = 1.0 - pow(a->beta1, (double)a->step);
-    const double bc2 = 1.0 - pow(a->beta2, (double)a->step);
-    k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     k.omb1 = (float)(1.0 - a->beta1);
     k.omb2 = (float)(1.0 - a->beta2);
     long long blocks = 0;
     for (int t = 0; t < a->num_tensors; ++t) {
         if (a->numel[t] < 0) return FDGS_EINVAL;
         if (a->numel[t] > 0 && (!a->param[t] || !a->grad[t] || !a->exp_avg[t] || !a->exp_avg_sq[t])) return FDGS_EINVAL;
+        if (a->step[t] < 1) return FDGS_EINVAL;
+        const double bc1 = 1.0 - pow(a->beta1, (double)a->step[t]);
+        const double bc2 = 1.0 - pow(a->beta2, (double)a->step[t]);
         k.block_start[t] = (int)blocks;
         k.step_size[t] = (float)((double)a->lr[t] / bc1);
+        k.inv_sqrt_bc2[t] = (float)(1.0 / sqrt(bc2));
         blocks += (a->numel[t] + ADAM_PER_BLOCK - 1) / ADAM_PER_BLOCK;
         if (blocks > 0x7fffffffLL) return FDGS_EINVAL;
     }

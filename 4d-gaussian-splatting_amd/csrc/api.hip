@@ -11,4 +11,4 @@ extern "C" const char* fdgs_strerror(int status) {
     }
 }
 
-extern "C" int fdgs_abi_version(void) { return 15; }
+extern "C" int fdgs_abi_version(void) { return 16; }

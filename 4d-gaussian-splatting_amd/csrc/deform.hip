@@ -20,7 +20,6 @@
 // lookup instead of 16 strided lines), rebuilt from the parameter layout
 // [16][H][W] at the start of every call (9.5 MB, a few microseconds).
 #include "fdgs_common.h"
-#include <mutex>
 #include <cstdlib>
 #include <type_traits>
 
@@ -1129,26 +1128,10 @@ extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, i
 }
 
 // The HexPlane scatter (atomics-bound) and the weight-gradient products (matrix-core / memory-bound) only
-// depend on pass 1, not on each other: they are issued on two streams (fork after pass 1, join before
-// returning to the caller's stream order).  One helper stream and two events per device, created on first
-// use and kept for the life of the process; calls on the same device must not overlap in time.
-struct SideStream { hipStream_t stream; hipEvent_t fork, join; bool ok; };
-static SideStream* side_stream() {
-    static SideStream table[64];
-    static bool made[64];
-    static std::mutex mu;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!made[dev]) {
-        SideStream& t = table[dev];
-        t.ok = hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&t.join, hipEventDisableTiming) == hipSuccess;
-        made[dev] = true;
-    }
-    return table[dev].ok ? &table[dev] : nullptr;
-}
+// depend on pass 1, not on each other: when the caller lends a second stream and two events
+// (fdgs_deform_bwd_args.side_stream / fork_event / join_event) they are issued on two streams (fork after
+// pass 1, join before returning to the caller's stream order).  The library itself owns no stream and no event.
+struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
 
 extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     if (!a || a->num_points < 0 || !params_ok(&a->p)) return FDGS_EINVAL;
@@ -1397,7 +1380,9 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     };
     // Points are processed in chunks: each chunk's a1 / dh1 operands are consumed by the weight-gradient
     // products right after they are produced and the workspace holds one chunk only.
-    SideStream* side = getenv("FDGS_SINGLE_STREAM") ? nullptr : side_stream();
+    SideStream side_handles{(hipStream_t)a->side_stream, (hipEvent_t)a->fork_event, (hipEvent_t)a->join_event};
+    SideStream* side = (a->side_stream && a->fork_event && a->join_event && a->side_stream != stream &&
+                        !getenv("FDGS_SINGLE_STREAM")) ? &side_handles : nullptr;
     static const int kdim[5] = {3, 3, 4, 1, 48};
     const float* gs[5] = {a->g_xyz, a->g_scales, a->g_rotations, a->g_opacity, a->g_shs};
     const int chunk_pts = bwd_chunk_points(n);

@@ -93,7 +93,8 @@ class DeformBwdArgs(C.Structure):
     _fields_ = [("num_points", c_i32), ("p", DeformParams),
                 ("xyz", c_p), ("time", c_p), ("time_scalar", c_f), ("hidden", c_p), ("act", c_p), ("mask", c_p), ("yhid", c_p), ("yfeat", c_p), ("planes_channel_last", c_p),
                 ("g_xyz", c_p), ("g_scales", c_p), ("g_rotations", c_p), ("g_opacity", c_p), ("g_shs", c_p),
-                ("d_xyz", c_p), ("dp", DeformParamGrads), ("workspace", c_p), ("workspace_bytes", c_sz)]
+                ("d_xyz", c_p), ("dp", DeformParamGrads), ("workspace", c_p), ("workspace_bytes", c_sz),
+                ("side_stream", c_p), ("fork_event", c_p), ("join_event", c_p)]
 
 
 class HexFeaturesArgs(C.Structure):
@@ -176,7 +177,7 @@ ADAM_MAX_TENSORS = 48
 
 
 class AdamArgs(C.Structure):
-    _fields_ = [("num_tensors", c_i32), ("step", c_i32), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+    _fields_ = [("num_tensors", c_i32), ("step", c_i32 * ADAM_MAX_TENSORS), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("lr", c_f * ADAM_MAX_TENSORS), ("numel", c_i64 * ADAM_MAX_TENSORS),
                 ("param", c_p * ADAM_MAX_TENSORS), ("grad", c_p * ADAM_MAX_TENSORS),
                 ("exp_avg", c_p * ADAM_MAX_TENSORS), ("exp_avg_sq", c_p * ADAM_MAX_TENSORS)]
@@ -219,7 +220,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 def _load():
@@ -281,3 +282,25 @@ def require_gpu(*tensors):
 
 def stream_ptr():
     return torch.cuda.current_stream().cuda_stream
+
+
+_SIDE = {}
+
+
+def side_resources():
+    """A helper stream and two events for the calls enqueued on torch's current stream (fdgs_deform_bwd runs its
+    HexPlane scatter beside its weight-gradient products when it is lent them).  The library owns no stream: these
+    are PyTorch's, one triple per (device, stream), kept for the life of the process; calls on different streams
+    get different triples and may overlap."""
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, cur.cuda_stream)
+    res = _SIDE.get(key)
+    if res is None:
+        with torch.cuda.device(cur.device):
+            side = torch.cuda.Stream()
+            fork, join = torch.cuda.Event(), torch.cuda.Event()
+            fork.record(cur)        # torch creates the hipEvent_t on first use
+            join.record(side)
+        res = _SIDE[key] = (side, fork, join)
+    side, fork, join = res
+    return side.cuda_stream, fork.cuda_event, join.cuda_event

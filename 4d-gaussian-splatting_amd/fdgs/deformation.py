@@ -22,7 +22,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, adam
 from ._lib import lib, ptr, check, stream_ptr
 
 PLANE_AXES = list(itertools.combinations(range(4), 2))
@@ -241,6 +241,7 @@ class _DeformFunction(torch.autograd.Function):
         ctx.net = net
         ctx.time_scalar = time_scalar
         ctx.param_versions = [p._version for p in params]
+        ctx.param_generation = adam.GENERATION[0]       # FusedAdam writes through raw pointers: no version bump
         ctx.matmul = MATMUL
         ctx.save_for_backward(xyz_c, time_c, hidden, ws, act, mask, yhid, yfeat)
         return tuple(outs)
@@ -269,12 +270,13 @@ class _DeformFunction(torch.autograd.Function):
         G = _fill_params(net, grads)
         d_xyz = torch.empty_like(xyz_c)
         # the forward's channel-last plane copies are still valid if no parameter was written since
-        unchanged = all(p._version == v for p, v in zip(params, ctx.param_versions))
+        unchanged = (ctx.param_generation == adam.GENERATION[0]
+                     and all(p._version == v for p, v in zip(params, ctx.param_versions)))
         planes_cl = ptr(fwd_ws) if unchanged else None
         ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformBwdArgs(N, P, ptr(xyz_c), ptr(time_c), ctx.time_scalar, ptr(hidden), ptr(act), ptr(mask), ptr(yhid), ptr(yfeat), planes_cl, ptr(g_xyz), ptr(g_sc), ptr(g_ro),
-                               ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes)
+                               ptr(g_op), ptr(g_sh), ptr(d_xyz), G, ptr(ws), ws_bytes, *_lib.side_resources())
         g_sh_out, pending = g_sh, None
         if RESIDUAL_GRAD_HOOK is not None:
             g_sh_out = g_sh.clone()          # the kernels below still read this rank's own cotangent

@@ -92,38 +92,29 @@ class GradBucket:
         self.numel = sum(p.numel() for p in self.params)
         self.flat = None
 
-    def _ensure(self, device):
-        if self.flat is None or self.flat.numel() != self.numel or self.flat.device != device:
-            self.flat = torch.empty(self.numel, device=device, dtype=torch.float32)
-
     def rebuild(self, params):
         """After densification / pruning changed N."""
         self.__init__(params)
 
     def allreduce_(self, group=None):
-        """SUM all-reduce of every .grad (missing grads count as zero), written back in place."""
-        if not self.params:
+        """SUM all-reduce of every .grad that exists, written back in place.  A tensor without a gradient stays
+        without one (the optimizer then skips it and does not count a step for it, as torch.optim.Adam does for
+        the deformation field during the coarse stage).  Which tensors have gradients must be the same on every
+        rank: it follows from the stage, and a rank without views fills in zeros for that same set."""
+        have = [p for p in self.params if p.grad is not None]
+        if not have:
             return
-        self._ensure(self.params[0].device)
+        sizes = [p.numel() for p in have]
+        total = sum(sizes)
+        dev = have[0].device
+        if self.flat is None or self.flat.numel() < total or self.flat.device != dev:
+            self.flat = torch.empty(max(total, self.numel), device=dev, dtype=torch.float32)
+        flat = self.flat[:total]
         # gather and scatter with one concatenation and one multi-tensor copy (not a launch pair per tensor)
-        sizes = [p.numel() for p in self.params]
-        views = self.flat.split_with_sizes(sizes)
-        missing = [i for i, p in enumerate(self.params) if p.grad is None]
-        if missing:
-            for i in missing:
-                views[i].zero_()
-            present = [i for i, p in enumerate(self.params) if p.grad is not None]
-            if present:
-                torch._foreach_copy_([views[i] for i in present], [self.params[i].grad.reshape(-1) for i in present])
-        else:
-            torch.cat([p.grad.reshape(-1) for p in self.params], out=self.flat)
+        torch.cat([p.grad.reshape(-1) for p in have], out=flat)
         if is_dist():
-            all_reduce_(self.flat, dist.ReduceOp.SUM, group)
-        for i in missing:
-            self.params[i].grad = views[i].view_as(self.params[i]).clone()
-        have = [i for i in range(len(self.params)) if i not in set(missing)]
-        if have:
-            torch._foreach_copy_([self.params[i].grad for i in have], [views[i].view_as(self.params[i]) for i in have])
+            all_reduce_(flat, dist.ReduceOp.SUM, group)
+        torch._foreach_copy_([p.grad for p in have], [v.view_as(p) for p, v in zip(have, flat.split_with_sizes(sizes))])
 
 
 def reduce_densification_stats(radii, visibility, viewspace_grad, group=None):

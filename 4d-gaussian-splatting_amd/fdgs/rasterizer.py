@@ -166,11 +166,16 @@ class _RasterizeGaussians(torch.autograd.Function):
         st = rasterize_forward(m3, sh, op, sc, ro, S, colors_precomp=cp, cov3D_precomp=cv, activations=activations)
         ctx.S = S
         ctx.activations = activations
+        # the context keeps what the backward reads (geom, list, ranges, final_T, n_contrib) and none of the
+        # outputs: an output held by its own grad_fn's context would be a reference cycle through C++ that Python's
+        # collector cannot see, leaking the images and lists of every grad-enabled render that is never backpropagated
+        color, radii, depth = st.color, st.radii, st.depth
+        st.color = st.radii = st.depth = st.tiles_touched = st.point_offsets = None
         ctx.st = st
         ctx.inputs = (m3, sh, cp, sc, ro, cv)
         ctx.op_shape = opacities.shape
-        ctx.mark_non_differentiable(st.radii, st.depth)
-        return st.color, st.radii, st.depth
+        ctx.mark_non_differentiable(radii, depth)
+        return color, radii, depth
 
     @staticmethod
     def backward(ctx, grad_color, _grad_radii, _grad_depth):

@@ -29,8 +29,9 @@ class TrainStep:
         self.g, self.deforms, self.bg, self.stage = gaussians, deforms, background, stage
         self.lambda_dssim = float(lambda_dssim)     # configs/train/dynerf.yaml:36 ships 0
         self.last_psnr = None                       # fdgs_trainer.py:131: mean PSNR of the local views, on device
-        # fdgs_trainer.py:133-135: the grid regulariser joins the loss in the fine stage when its weight is set
-        self.regulation = tuple(regulation) if (regulation and "fine" in stage and regulation[0] != 0) else None
+        # fdgs_trainer.py:133-135: the grid regulariser joins the loss in the fine stage when its weight is set;
+        # the stage is looked at per call, so one object (one optimizer, one set of moments) spans coarse -> fine
+        self.regulation_weights = tuple(regulation) if (regulation and regulation[0] != 0) else None
         df = deforms.deformation_fields
         groups = [   # configs/train/dynerf.yaml:23-35, fdgs_trainer.py:262-272
             {"params": [gaussians._xyz], "lr": 0.00016 * lr_scale, "name": "xyz"},
@@ -92,10 +93,20 @@ class TrainStep:
         self.surgery().reset_opacity()
         self._bind_parameters()
 
-    def __call__(self, global_views, iteration=None):
+    @property
+    def regulation(self):
+        return self.regulation_weights if "fine" in self.stage else None
+
+    def __call__(self, global_views, iteration=None, stage=None, before_optimizer_step=None):
         """global_views: the whole batch (identical on every rank); returns the local loss value tensor.
         iteration: the trainer's counter; when given, the scheduled learning rates are set first
-        (fdgs_trainer.py:216, 288-302)."""
+        (fdgs_trainer.py:216, 288-302).
+        stage: "coarse" / "fine" for this and the following calls (fdgs_trainer.py:114); None keeps the last one.
+        before_optimizer_step: callable(self) run between the statistics update and the optimizer step - where the
+        reference densifies, prunes and resets opacities (fdgs_trainer.py:191-200, then :203-205).  Tensors the
+        surgery replaces have no gradient afterwards and are not stepped in that iteration, as in the reference."""
+        if stage is not None:
+            self.stage = stage
         if iteration is not None:
             self.learning_rates.update(self.optimizer, iteration)
         views = dp.shard_views(global_views)
@@ -154,10 +165,16 @@ class TrainStep:
             vgrad = torch.zeros_like(vsp_list[0])
             for v in vsp_list:
                 vgrad = vgrad + v.grad
-        else:   # a rank without views this step still takes part in the collectives
+        else:   # a rank without views this step still takes part in the collectives, with zeros for exactly the
+            # tensors that get a gradient in this stage on the other ranks (the deformation field: fine stage only)
             radii = torch.zeros(n, dtype=torch.int32, device=dev)
             vis = torch.zeros(n, dtype=torch.bool, device=dev)
             vgrad = torch.zeros(n, 3, device=dev)
+            if dp.is_dist():
+                gaussian_ids = {id(t) for t in self.g.parameters()} if hasattr(self.g, "parameters") else set()
+                for p in self.params:
+                    if p.requires_grad and p.grad is None and ("fine" in self.stage or id(p) in gaussian_ids):
+                        p.grad = torch.zeros_like(p)
         if dp.is_dist():
             # `early` is the same on every rank: the hook is armed only for one view per rank, and it fires
             # once per fine-stage render
@@ -166,6 +183,8 @@ class TrainStep:
             vis = radii > 0
         # fdgs_trainer.py:181-182, gaussian_model.py:182-184 in one launch
         losses.add_densification_stats(radii, vgrad, self.xyz_gradient_accum, self.denom, self.max_radii2D)
+        if before_optimizer_step is not None:
+            before_optimizer_step(self)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         out = loss.detach() if loss is not None else torch.zeros((), device=dev)

@@ -4,10 +4,11 @@
  * One shared library, libfdgs.so.  Plain pointers and sizes only: every pointer
  * below is a DEVICE pointer unless its comment says "host".  The caller owns
  * every buffer (inputs, outputs, workspaces); the library allocates nothing,
- * keeps no state between calls, starts no threads and no streams.  Every entry
- * point enqueues its kernels on the HIP stream passed in (`stream` is a
- * hipStream_t, spelled void* so that this header needs no HIP include) and
- * returns without synchronising.  Return value: FDGS_OK (0) or a negative
+ * keeps no state between calls, starts no threads, creates no streams and no
+ * events: every entry point is re-entrant.  Every entry point enqueues its
+ * kernels on the HIP stream passed in (`stream` is a hipStream_t, spelled
+ * void* so that this header needs no HIP include; fdgs_deform_bwd may also use
+ * a second stream the caller lends it) and returns without synchronising.  Return value: FDGS_OK (0) or a negative
  * fdgs_status; fdgs_strerror() names it.  No C++ exception crosses the ABI.
  *
  * What each entry point replaces in the reference (paths relative to the
@@ -276,6 +277,13 @@ typedef struct {
     fdgs_deform_param_grads dp;      /* accumulated into (+=); caller zeroes; entries may be NULL to skip */
     void* workspace;                 /* fdgs_deform_bwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
+    /* Optional, caller-owned, all three or none: a second hipStream_t and two hipEvent_t (created with
+     * hipEventDisableTiming or not) on the device of `stream`.  With them the HexPlane scatter runs on
+     * side_stream beside the weight-gradient products: the call records fork_event on `stream`, makes side_stream
+     * wait for it, and makes `stream` wait for join_event before it returns, so the caller still sees one
+     * stream-ordered operation.  NULL: everything is enqueued on `stream`.  Two calls that may overlap in time
+     * (different streams, different threads) need their own triple and their own workspace.                */
+    void* side_stream; void* fork_event; void* join_event;
 } fdgs_deform_bwd_args;
 
 size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points);
@@ -368,11 +376,13 @@ int fdgs_knn_mean_dist2(const float* points, int32_t num_points, float* mean_dis
  * the optimizer the reference builds at src/runner/fdgs_trainer.py:262-274 (eps 1e-15, one learning
  * rate per parameter group) and steps at :204.
  *   m += (1-beta1)(g-m);  v = beta2 v + (1-beta2) g^2;
- *   p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)                                */
+ *   p -= lr/(1-beta1^step) * m / (sqrt(v)/sqrt(1-beta2^step) + eps)      (step: the tensor's own count)  */
 #define FDGS_ADAM_MAX_TENSORS 48
 typedef struct {
     int32_t num_tensors;
-    int32_t step;                                    /* 1-based, shared by all tensors */
+    int32_t step[FDGS_ADAM_MAX_TENSORS];             /* 1-based, per tensor: torch.optim.Adam counts a tensor's steps from
+                                                        its first gradient (state[p]["step"]), so tensors that join later
+                                                        (the deformation field after the coarse stage) start at 1 */
     double beta1, beta2, eps;                        /* doubles, as Python holds them: 1-beta is formed before rounding to fp32 */
     float lr[FDGS_ADAM_MAX_TENSORS];
     int64_t numel[FDGS_ADAM_MAX_TENSORS];

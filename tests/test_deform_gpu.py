@@ -175,3 +175,44 @@ def test_plane_regulation_vs_reference_golden(case):
     check_regulation_against_golden(case, float(val), [g.cpu() for g in once])
     losses.add_regulation_grad_(net, *REG_WEIGHTS, want_loss=False)          # accumulates: x + x is exact
     assert all(torch.equal(p.grad, 2.0 * g) for p, g in zip(planes, once))
+
+
+def test_two_backward_calls_on_two_streams_overlap_safely():
+    """fdgs_deform_bwd keeps no state of its own: the helper stream and events it forks onto are lent by the caller,
+    one triple per calling stream.  Two forward + backward passes enqueued on two streams (they overlap on the
+    device: each runs for more than a millisecond, the host enqueues the second within that time) must give the
+    results of the same passes run one after the other."""
+    import copy
+    from fdgs import _lib
+    dev = torch.device("cuda:0")
+    net_a, _ = _module("dynerf", dev)
+    net_b = copy.deepcopy(net_a)
+    n = 200000
+    gen = torch.Generator().manual_seed(21)
+
+    def inputs(scale):
+        lo, hi = -1.5 * scale, 1.5 * scale
+        xyz = lo + (hi - lo) * torch.rand(n, 3, generator=gen)
+        return [xyz.to(dev).requires_grad_(True)] + [torch.randn(s, generator=gen).to(dev).requires_grad_(True)
+                                                     for s in ((n, 3), (n, 4), (n, 1), (n, 16, 3))]
+    ins_a, ins_b = inputs(1.0), inputs(0.7)
+    cots = [torch.randn(s, generator=gen).to(dev) for s in ((n, 3), (n, 3), (n, 4), (n, 1), (n, 16, 3))]
+
+    def run(net, ins, t):
+        outs = net(*ins, t)
+        params = [p for p in net.parameters() if p.requires_grad]
+        return [o.detach() for o in outs] + list(torch.autograd.grad(outs, ins + params, cots))
+
+    ref_a, ref_b = run(net_a, ins_a, 0.25), run(net_b, ins_b, 0.75)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    before = len(_lib._SIDE)
+    with torch.cuda.stream(s1):
+        got_a = run(net_a, ins_a, 0.25)
+    with torch.cuda.stream(s2):
+        got_b = run(net_b, ins_b, 0.75)
+    torch.cuda.synchronize()
+    assert len(_lib._SIDE) == before + 2          # each calling stream got its own helper stream and events
+    for ref, got in ((ref_a, got_a), (ref_b, got_b)):
+        for r, g in zip(ref, got):
+            assert float((r - g).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-12     # atomics: order noise only

@@ -77,8 +77,10 @@ def test_two_ranks_match_one_rank(tmp_path):
     loss = sum(_view_loss(params, v) for v in views) / len(views)
     loss.backward()
     for p, g in zip(params, got["grads"]):
-        ref = p.grad if p.grad is not None else torch.zeros_like(p)
-        assert torch.allclose(g, ref, rtol=1e-5, atol=1e-7)
+        if p.grad is None:      # a tensor no rank has a gradient for stays without one (the optimizer skips it)
+            assert g is None
+        else:
+            assert torch.allclose(g, p.grad, rtol=1e-5, atol=1e-7)
     stats = [_view_stats(v) for v in views]
     assert torch.equal(got["radii"], torch.stack([s[0] for s in stats]).max(0).values)      # integer: bitwise
     assert torch.equal(got["vis"], torch.stack([s[1] for s in stats]).any(0))

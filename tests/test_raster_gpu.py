@@ -224,6 +224,53 @@ def test_fused_adam_matches_torch():
             assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max()), key
 
 
+def test_fused_adam_counts_steps_per_tensor_and_round_trips_its_state():
+    """A tensor that gets its first gradient after k steps (the deformation field after the coarse stage,
+    fdgs_trainer.py:114) starts its bias correction at step 1, as torch.optim.Adam's per-parameter
+    state[p]["step"] does; a tensor without a gradient is not stepped.  state_dict() has torch's layout: it
+    loads into torch.optim.Adam and back, and training continues identically."""
+    from fdgs.adam import FusedAdam
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(12)
+    shapes = [(500, 3), (128, 128), (48, 128)]
+    lrs = [1.6e-4, 1.6e-4, 1.6e-3]
+    ref_p = [torch.randn(s, generator=gen).to(dev).requires_grad_(True) for s in shapes]
+    our_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+
+    def make(cls, ps):
+        return cls([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(ps, lrs))],
+                   lr=0.0, eps=1e-15)
+    ref, our = make(torch.optim.Adam, ref_p), make(FusedAdam, our_p)
+
+    def one_step(ro, oo, rp, op, step, late_from=5):
+        for i, (a, b) in enumerate(zip(rp, op)):
+            if i > 0 and step < late_from:          # tensors 1 and 2 join at step `late_from`
+                a.grad = b.grad = None
+                continue
+            g = torch.randn(a.shape, generator=gen).to(dev)
+            a.grad, b.grad = g.clone(), g
+        ro.step()
+        oo.step()
+
+    for step in range(8):
+        one_step(ref, our, ref_p, our_p, step)
+    torch.cuda.synchronize()
+    assert our.state[our_p[0]]["step"] == 8 and our.state[our_p[1]]["step"] == 3
+    for a, b in zip(ref_p, our_p):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
+    # round trip through torch's own loader, in both directions
+    ref2_p = [p.detach().clone().requires_grad_(True) for p in our_p]
+    our2_p = [p.detach().clone().requires_grad_(True) for p in our_p]
+    ref2, our2 = make(torch.optim.Adam, ref2_p), make(FusedAdam, our2_p)
+    ref2.load_state_dict(our.state_dict())
+    our2.load_state_dict(ref.state_dict())
+    assert our2.state[our2_p[1]]["step"] == 3 and float(ref2.state[ref2_p[1]]["step"]) == 3.0
+    for step in range(8, 11):
+        one_step(ref2, our2, ref2_p, our2_p, step)
+    for a, b in zip(ref2_p, our2_p):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
+
+
 def test_l1_loss_and_densification_stats_match_torch():
     """fdgs.losses: scale * mean|a - b| with its gradient (src/model/losses.py:7-8) and the statistics update of
     src/runner/fdgs_trainer.py:181-182 against the PyTorch expressions; sizes that exercise the 16-byte path,

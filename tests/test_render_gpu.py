@@ -136,3 +136,53 @@ def test_render_empty_and_single_gaussian_scene(n):
             assert torch.equal(pkg["render"], bg.view(3, 1, 1).expand(3, 120, 160))
         else:
             assert torch.isfinite(g._xyz.grad).all()
+
+
+def test_saved_scene_plays_back_through_the_hip_path(tmp_path):
+    """The reference's playback (render.py:114-142): Scene.load reads point_cloud.ply and deformation.pth
+    (src/scene/scene.py:35-41, gaussian_model.py:131-171, deformation_wrapper.py:31-41) into fresh objects and
+    render() draws them.  Everything stored is float32, so a saved and re-loaded scene renders bit-identically
+    (images, depth, radii) to the scene in memory, at several time stamps."""
+    import gc
+    from fdgs import io, scene_synth as ss
+    from fdgs.deformation import DeformationFields
+    from fdgs.renderer import render
+    from fdgs.train_step import DeformHolder
+    cam, pc, deforms, bg = _scene(n=20000, w=320, h=240)
+    net = deforms.deformation_fields
+    net.deformation_net.set_aabb(list(ss.SCENE_MAX), list(ss.SCENE_MIN))
+    model_dir = str(tmp_path / "point_cloud" / "iteration_7")
+    io.save_ply(model_dir + "/point_cloud.ply", pc._xyz, pc._features_dc, pc._features_rest, pc._opacity, pc._scaling,
+                pc._rotation)
+    table = torch.ones(20000, dtype=torch.bool, device="cuda:0")
+    io.save_deformation(model_dir, net, table, torch.zeros(20000, 3, device="cuda:0"))
+
+    dev = torch.device("cuda:0")
+    loaded = io.load_ply(model_dir + "/point_cloud.ply", max_sh_degree=3, device=dev)
+    pc2 = ss.GaussianParams(1, device=dev, requires_grad=False)       # fresh container, overwritten below
+    pc2._xyz, pc2._features_dc, pc2._features_rest = loaded["xyz"], loaded["features_dc"], loaded["features_rest"]
+    pc2._opacity, pc2._scaling, pc2._rotation = loaded["opacity"], loaded["scaling"], loaded["rotation"]
+    net2 = DeformationFields(ss.DYNERF_NET_KWARGS).to(dev)           # fresh random weights, then the file's
+    table2, accum2 = io.load_deformation(model_dir, net2, 20000, device=dev)
+    assert torch.equal(table2, table) and accum2.shape == (20000, 3)
+    for a, b in zip(pc.parameters(), pc2.parameters()):
+        assert torch.equal(a.detach(), b)
+    with torch.no_grad():
+        for t in (0.0, 0.37, 299 / 300):
+            cam.time = t
+            a = render(cam, pc, deforms, bg)
+            b = render(cam, pc2, DeformHolder(net2), bg)
+            assert torch.equal(a["radii"], b["radii"]) and int((a["radii"] > 0).sum()) > 1000
+            assert torch.equal(a["render"], b["render"]) and torch.equal(a["depth"], b["depth"])
+    # a grad-enabled render that is never backpropagated must not pin its buffers (no cycle through the context)
+    gc.collect()
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    for _ in range(3):
+        render(cam, pc, deforms, bg)
+    gc.disable()
+    try:
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated() <= base + (1 << 20)
+    finally:
+        gc.enable()
