@@ -7,8 +7,9 @@ extern "C" const char* fdgs_strerror(int status) {
         case FDGS_EINVAL: return "invalid argument (null pointer, negative size or unsupported configuration)";
         case FDGS_ELAUNCH: return "kernel launch rejected by the HIP runtime";
         case FDGS_EWORKSPACE: return "workspace too small";
+        case FDGS_ETOOLARGE: return "input larger than the entry point's built-in limit";
         default: return "unknown fdgs status";
     }
 }
 
-extern "C" int fdgs_abi_version(void) { return 16; }
+extern "C" int fdgs_abi_version(void) { return 17; }

@@ -5,6 +5,7 @@
 //     Gaussians (src/runner/fdgs_trainer.py:181-182, src/model/gaussian_model.py:182-184).
 // Memory-bound; in PyTorch they are about thirty small launches per iteration.
 #include "fdgs_common.h"
+#include <mutex>
 
 #define L1_THREADS 256
 #define L1_PER_THREAD 16                      // floats per thread per input (4 x float4)
@@ -96,6 +97,45 @@ extern "C" int fdgs_l1_loss_fwd(const fdgs_l1_fwd_args* a, void* stream) {
     hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)blocks), dim3(L1_THREADS), 0, s, *a);
     FDGS_CHECK_LAUNCH();
     hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(L1_THREADS), 0, s, *a, (int)blocks);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}
+
+// ---- the same two launches with the partial sums in a scratch array built into the library (no allocation) ----
+// One copy of the array per GPU that runs the library; `scratch` itself is only a host-side handle of the
+// symbol: its device address is looked up once per device and that pointer is what the kernels receive.
+static __device__ __align__(256) float scratch[2 * FDGS_L1_STATIC_MAX_PARTIALS];
+
+#define L1_MAX_DEVICES 64
+static std::mutex scratch_mu;
+static float* scratch_ptr[L1_MAX_DEVICES];        // device address of `scratch` on each device, 0 until looked up
+
+static int scratch_address(float** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= L1_MAX_DEVICES) return FDGS_ELAUNCH;
+    std::lock_guard<std::mutex> lock(scratch_mu);
+    if (!scratch_ptr[dev]) {
+        float* p = nullptr;
+        if (hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return FDGS_ELAUNCH;
+        scratch_ptr[dev] = p;
+    }
+    *out = scratch_ptr[dev];
+    return FDGS_OK;
+}
+
+extern "C" int fdgs_l1_loss_fwd_static(const fdgs_l1_fwd_args* a, void* stream) {
+    if (!a || a->n <= 0 || !a->a || !a->b || !a->loss) return FDGS_EINVAL;
+    if (a->n > FDGS_L1_STATIC_MAX_N) return FDGS_ETOOLARGE;
+    static_assert((long long)L1_THREADS * L1_PER_THREAD == 4096, "FDGS_L1_STATIC_MAX_N assumes 4096 floats per partial");
+    const size_t blocks = fdgs_l1_loss_partials(a->n);          // <= FDGS_L1_STATIC_MAX_PARTIALS by the check above
+    if (blocks > FDGS_L1_STATIC_MAX_PARTIALS) return FDGS_ETOOLARGE;
+    fdgs_l1_fwd_args k = *a;
+    int rc = scratch_address(&k.partial);
+    if (rc != FDGS_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)blocks), dim3(L1_THREADS), 0, s, k);
+    FDGS_CHECK_LAUNCH();
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(L1_THREADS), 0, s, k, (int)blocks);
     FDGS_CHECK_LAUNCH();
     return FDGS_OK;
 }

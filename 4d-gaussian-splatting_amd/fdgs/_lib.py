@@ -64,6 +64,9 @@ class PreprocessBwdArgs(C.Structure):
                 ("activations", c_i32)]
 
 
+L1_STATIC_MAX_N = 16384 * 4096          # FDGS_L1_STATIC_MAX_N
+ETOOLARGE = -4
+
 ACT_SCALE_EXP, ACT_ROTATION_NORMALIZE, ACT_OPACITY_SIGMOID = 1, 2, 4
 
 
@@ -202,6 +205,7 @@ SYMBOLS = {
     "fdgs_l1_loss_partials": (c_sz, [c_i64]),
     "fdgs_l1_loss_fwd": (C.c_int, [C.POINTER(L1FwdArgs), c_p]),
     "fdgs_l1_loss_bwd": (C.c_int, [C.POINTER(L1BwdArgs), c_p]),
+    "fdgs_l1_loss_fwd_static": (C.c_int, [C.POINTER(L1FwdArgs), c_p]),
     "fdgs_densify_stats": (C.c_int, [C.POINTER(DensifyStatsArgs), c_p]),
     "fdgs_plane_reg_partials": (c_sz, [c_i32]),
     "fdgs_plane_regulation": (C.c_int, [C.POINTER(PlaneRegArgs), c_p]),
@@ -220,7 +224,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 def _load():

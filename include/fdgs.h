@@ -43,7 +43,8 @@ typedef enum {
     FDGS_OK = 0,
     FDGS_EINVAL = -1,      /* null pointer, negative size, unsupported configuration */
     FDGS_ELAUNCH = -2,     /* a kernel launch was rejected by the runtime            */
-    FDGS_EWORKSPACE = -3   /* workspace smaller than fdgs_*_workspace_bytes() asks   */
+    FDGS_EWORKSPACE = -3,  /* workspace smaller than fdgs_*_workspace_bytes() asks   */
+    FDGS_ETOOLARGE = -4    /* input larger than a fixed built-in limit of the entry point */
 } fdgs_status;
 
 const char* fdgs_strerror(int status);
@@ -328,6 +329,18 @@ typedef struct {
 size_t fdgs_l1_loss_partials(int64_t n);
 int fdgs_l1_loss_fwd(const fdgs_l1_fwd_args* a, void* stream);
 int fdgs_l1_loss_bwd(const fdgs_l1_bwd_args* a, void* stream);
+
+/* fdgs_l1_loss_fwd for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): it has no counterpart in the reference.  Same arguments and the same
+ * result, bit for bit, as fdgs_l1_loss_fwd, but `partial` is ignored (may be NULL): the per-workgroup partial sums
+ * go to a scratch array built into the library, one copy per GPU (128 KiB, held until the process ends).
+ * Limit: n <= FDGS_L1_STATIC_MAX_N, larger n returns FDGS_ETOOLARGE.  Calls no allocating routine; the first call
+ * on a device looks the array's address up once (hipGetSymbolAddress) and keeps it.  Every call on a GPU shares that
+ * GPU's array: calls that may overlap in time on one GPU (two streams, two threads) race and must be serialised by
+ * the caller; nothing has to start at zero (every partial that is read was written by the same call).          */
+#define FDGS_L1_STATIC_MAX_PARTIALS 16384
+#define FDGS_L1_STATIC_MAX_N ((int64_t)FDGS_L1_STATIC_MAX_PARTIALS * 4096)      /* 67,108,864 floats */
+int fdgs_l1_loss_fwd_static(const fdgs_l1_fwd_args* a, void* stream);
 
 /* ---- densification statistics of one iteration (src/runner/fdgs_trainer.py:181-182,
  * src/model/gaussian_model.py:182-184): for every Gaussian with radii > 0,
