@@ -1,0 +1,198 @@
+"""One training view as a straight sequence of C-ABI calls on persistent buffers.
+
+`render()` (fdgs/renderer.py) keeps the reference's interface: autograd Functions, fresh tensors per call,
+a Python frame per stage.  On a 3 ms iteration that interface costs a tenth of the time in host work while the
+GPU waits.  The training loop of the reference (src/runner/fdgs_trainer.py:239-248, :127-140) always runs the same
+chain - render, L1 loss, backward - so `ViewPipeline.run` issues exactly that chain: deformation forward,
+rasterizer forward, L1 loss (+ PSNR), L1 backward, rasterizer backward, deformation backward, with every buffer
+allocated once per (N, image size) and every argument struct built once.  Same kernels, same arithmetic and the
+same results as the autograd route (tests/test_pipeline_gpu.py compares them); gradients are returned as tensors
+for the caller to attach to the parameters.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib, deformation as _deformation, rasterizer as _rasterizer
+from ._lib import lib, ptr
+
+
+class ViewGrads:
+    """Gradients of one view: per-Gaussian tensors (raw-parameter space) and the deformation field's flat buffer."""
+    __slots__ = ("xyz", "scaling", "rotation", "opacity", "shs", "means2D", "radii", "loss", "psnr")
+
+
+class ViewPipeline:
+    def __init__(self, gaussians, deformation_fields, background):
+        self.g = gaussians
+        self.net = deformation_fields            # DeformationFields, or None (coarse-only use)
+        self.bg = background.detach().to(torch.float32).contiguous()
+        self.N = self.W = self.H = -1
+        self.capacity = 0
+        self._one = None
+
+    # ------------------------------------------------------------------------------------------------------
+    def usable(self, stage):
+        g = self.g
+        return (g.scaling_activation is torch.exp and g.opacity_activation is torch.sigmoid
+                and g.rotation_activation is torch.nn.functional.normalize
+                and ("coarse" in stage or self.net is not None))
+
+    def _alloc(self, N, W, H, dev):
+        f32, i32 = torch.float32, torch.int32
+        e = lambda *s, dtype=f32: torch.empty(*s, device=dev, dtype=dtype)
+        self.N, self.W, self.H = N, W, H
+        gx, gy = (W + _lib.TILE - 1) // _lib.TILE, (H + _lib.TILE - 1) // _lib.TILE
+        # deformation outputs and what its backward needs
+        self.d_out = [e(N, 3), e(N, 3), e(N, 4), e(N, 1), e(N, 16, 3)]
+        self.shs_in = e(N, 16, 3)
+        self.act = e((N + 31) // 32 * 32, 192)
+        self.yhid = e((N + 15) // 16 * 16 + 16, 192)
+        self.mask = e(N, 12, dtype=torch.int64)
+        self.yfeat = e((N + 15) // 16 * 16 + 16, 48)
+        self.hidden = None
+        # rasterizer
+        self.geom = e(N, _lib.GEOM_FLOATS)
+        self.radii = e(N, dtype=i32)
+        self.tiles_touched = e(N, dtype=i32)
+        self.point_offsets = e(N, dtype=i32)
+        self.scan_ws = e(max(1, lib.fdgs_raster_scan_workspace_bytes(N) // 4), dtype=i32)
+        self.color = e(3, H, W)
+        self.depth = e(1, H, W)
+        self.final_T = e(H, W)
+        self.n_contrib = e(H, W, dtype=i32)
+        self.ranges = e(gx * gy, 2, dtype=i32)
+        n_img = 3 * H * W
+        self.loss = e(())
+        self.psnr = e(())
+        self.l1_partial = e(2 * lib.fdgs_l1_loss_partials(n_img))
+        self.grad_image = e(3, H, W)
+        # backward; two sets of per-Gaussian gradient buffers so that a second view can be added to the first
+        self.dgeom = torch.zeros(N, _lib.GEOM_FLOATS, device=dev, dtype=f32)
+        self.sets = [dict(xyz=e(N, 3), means3D=e(N, 3), means2D=e(N, 3), scaling=e(N, 3), rotation=e(N, 4),
+                          opacity=e(N, 1), shs=e(N, 16, 3)) for _ in range(2)]
+        self._one = torch.ones(1, device=dev, dtype=f32)
+        self.r_host = torch.empty(1, dtype=i32).pin_memory()
+        self._deform_ws = None
+        self._R_last = 0
+
+    def _list_buffers(self, R, dev):
+        if R <= self.capacity:
+            return
+        step = 1 << max(int(R).bit_length() - 3, 10)
+        cap = (R + step - 1) // step * step
+        self.capacity = cap
+        ws_bytes = lib.fdgs_raster_sort_workspace_bytes(cap)
+        self.keys_a = torch.empty(cap, device=dev, dtype=torch.int64)
+        self.vals_a = torch.empty(cap, device=dev, dtype=torch.int32)
+        self.keys_b = torch.empty(cap, device=dev, dtype=torch.int64)
+        self.vals_b = torch.empty(cap, device=dev, dtype=torch.int32)
+        self.sort_ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        self.sort_ws_bytes = ws_bytes
+
+    def _deform_buffers(self, P, N, dev):
+        fb = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), N)
+        bb = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
+        if self._deform_ws is None or self._deform_ws[0].numel() < fb or self._deform_ws[1].numel() < bb:
+            self._deform_ws = (torch.empty(max(fb, 16), device=dev, dtype=torch.uint8),
+                               torch.empty(max(bb, 16), device=dev, dtype=torch.uint8))
+        return self._deform_ws[0], fb, self._deform_ws[1], bb
+
+    # ------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def run(self, cam, gt, scale, stage, grad_set=0, deform_grads=None, want_psnr=True, sh_hook=None):
+        """Forward, loss and backward of one view.  gt: [3,H,W] float32 on the device.  scale: the view's share of
+        the batch loss (1 / views in the batch).  deform_grads: the 34 gradient tensors of the deformation field in
+        the order of fdgs.deformation._trainable, accumulated into (fine stage).  Returns a ViewGrads whose tensors
+        are this object's buffers of set `grad_set` (valid until that set is used again)."""
+        g = self.g
+        xyz = g._xyz.detach()
+        dev = xyz.device
+        N = xyz.shape[0]
+        W, H = int(cam.image_width), int(cam.image_height)
+        if (N, W, H) != (self.N, self.W, self.H):
+            self._alloc(N, W, H, dev)
+        fine = "fine" in stage
+        S = self.sets[grad_set]
+        sc, ro, op = g._scaling.detach(), g._rotation.detach(), g._opacity.detach()
+        torch.cat((g._features_dc.detach(), g._features_rest.detach()), dim=1, out=self.shs_in)
+        tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        vm = cam.world_view_transform
+        pm = cam.full_proj_transform
+        cp = cam.camera_center
+        acts = _lib.ACT_SCALE_EXP | _lib.ACT_ROTATION_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
+
+        if fine:
+            net = self.net.deformation_net
+            P = _deformation._fill_params(net)
+            split = P.matmul == _lib.MATMUL_SPLIT_BF16
+            if not split and self.hidden is None:
+                self.hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32)
+            fws, fws_bytes, bws, bws_bytes = self._deform_buffers(P, N, dev)
+            o = self.d_out
+            a = _lib.DeformFwdArgs(N, P, ptr(xyz), ptr(sc), ptr(ro), ptr(op), ptr(self.shs_in), None, float(cam.time),
+                                   ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), ptr(o[4]),
+                                   None if split else ptr(self.hidden), ptr(self.act) if split else None,
+                                   ptr(self.mask) if split else None, ptr(self.yhid) if split else None,
+                                   ptr(self.yfeat) if split else None, ptr(fws), fws_bytes)
+            _lib.call("fdgs_deform_fwd", a)
+            m3, scales, rots, opac, shs = o[0], o[1], o[2], o[3].reshape(-1), o[4]
+        else:
+            m3, scales, rots, opac, shs = xyz, sc, ro, op.reshape(-1), self.shs_in
+
+        sh_degree = int(g.active_sh_degree)
+        pa = _lib.PreprocessFwdArgs(N, sh_degree, W, H, tanx, tany, 1.0, ptr(vm), ptr(pm), ptr(cp), ptr(m3),
+                                    ptr(scales), ptr(rots), ptr(opac), ptr(shs), None, None, ptr(self.geom),
+                                    ptr(self.radii), ptr(self.tiles_touched), ptr(self.point_offsets),
+                                    ptr(self.scan_ws), acts)
+        _lib.call("fdgs_raster_preprocess_fwd", pa)
+        # the data-dependent list length R: one 4-byte device->host read (the step's only synchronisation)
+        self.r_host.copy_(self.point_offsets[N - 1:N], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        R = int(self.r_host[0])
+        _rasterizer.LAST_NUM_RENDERED = R
+        self._list_buffers(max(R, 1), dev)
+        _lib.call("fdgs_raster_bin_sort",
+                  _lib.BinSortArgs(N, W, H, R, ptr(self.geom), ptr(self.point_offsets), ptr(self.keys_a),
+                                   ptr(self.vals_a), ptr(self.keys_b), ptr(self.vals_b), ptr(self.ranges),
+                                   ptr(self.sort_ws), self.sort_ws_bytes))
+        plist = ptr(self.vals_b) if R > 0 else None
+        _lib.call("fdgs_raster_blend_fwd",
+                  _lib.BlendFwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.color),
+                                    ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib)))
+        n_img = 3 * H * W
+        _lib.call("fdgs_l1_loss_fwd", _lib.L1FwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(self.loss),
+                                                     ptr(self.l1_partial), ptr(self.psnr) if want_psnr else None))
+        _lib.call("fdgs_l1_loss_bwd", _lib.L1BwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(self._one),
+                                                     ptr(self.grad_image)))
+        self.dgeom.zero_()
+        _lib.call("fdgs_raster_blend_bwd",
+                  _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),
+                                    ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom)))
+        d_m3 = S["means3D"] if fine else S["xyz"]
+        _lib.call("fdgs_raster_preprocess_bwd",
+                  _lib.PreprocessBwdArgs(N, sh_degree, W, H, tanx, tany, 1.0, ptr(vm), ptr(pm), ptr(cp), ptr(m3),
+                                         ptr(scales), ptr(rots), ptr(shs), None, None, ptr(self.geom), ptr(self.dgeom),
+                                         ptr(d_m3), ptr(S["means2D"]), ptr(S["scaling"]), ptr(S["rotation"]),
+                                         ptr(S["opacity"]), ptr(S["shs"]), None, None, acts))
+        out = ViewGrads()
+        g_sh = S["shs"]
+        pending = None
+        if fine:
+            if sh_hook is not None:          # data parallel: the SH gradient is final here and can start travelling
+                g_sh = S["shs"].clone()      # the kernels below still read this rank's own cotangent
+                pending = sh_hook(g_sh)
+            G = _deformation._fill_params(net, deform_grads)
+            b = _lib.DeformBwdArgs(N, P, ptr(xyz), None, float(cam.time), None if split else ptr(self.hidden),
+                                   ptr(self.act) if split else None, ptr(self.mask) if split else None,
+                                   ptr(self.yhid) if split else None, ptr(self.yfeat) if split else None, ptr(fws),
+                                   ptr(S["means3D"]), ptr(S["scaling"]), ptr(S["rotation"]), ptr(S["opacity"]),
+                                   ptr(S["shs"]), ptr(S["xyz"]), G, ptr(bws), bws_bytes, *_lib.side_resources())
+            _lib.call("fdgs_deform_bwd", b)
+            if pending is not None:
+                pending.wait()
+        out.xyz, out.scaling, out.rotation, out.opacity = S["xyz"], S["scaling"], S["rotation"], S["opacity"]
+        out.shs, out.means2D, out.radii = g_sh, S["means2D"], self.radii
+        out.loss, out.psnr = self.loss, (self.psnr if want_psnr else None)
+        return out

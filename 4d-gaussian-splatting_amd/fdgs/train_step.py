@@ -52,6 +52,12 @@ class TrainStep:
         self.learning_rates = schedule.LearningRates(spatial_lr_scale=lr_scale)   # fdgs_trainer.py:275-286
         self._bind_parameters()
         self.early_exchange = os.environ.get("FDGS_DP_EARLY", "1") != "0"
+        # the straight C-ABI chain on persistent buffers (fdgs/pipeline.py) instead of render() + autograd;
+        # FDGS_PIPELINE=0 keeps the autograd route (same kernels, more host work)
+        from .pipeline import ViewPipeline
+        self.pipeline = ViewPipeline(gaussians, getattr(deforms, "deformation_fields", None), background)
+        self.use_pipeline = os.environ.get("FDGS_PIPELINE", "1") != "0"
+        self._dflat = None
         dp.broadcast_parameters(self.params)      # replicas start identical whatever the ranks' RNG state was
         n = gaussians._xyz.shape[0]
         dev = gaussians._xyz.device
@@ -93,6 +99,83 @@ class TrainStep:
         self.surgery().reset_opacity()
         self._bind_parameters()
 
+    # -- the per-view work, two routes to the same gradients ---------------------------------------------------
+    def _views_direct(self, views, scale, hook):
+        """fdgs/pipeline.py: the chain of C-ABI calls on persistent buffers; gradients attached to .grad here."""
+        if not views:
+            return None, None, None, None
+        g = self.g
+        fine = "fine" in self.stage
+        dgrads = None
+        if fine:
+            from . import deformation
+            net = self.deforms.deformation_fields.deformation_net
+            params = deformation._trainable(net)
+            order, sizes, shapes = net._fdgs_grad_order, net._fdgs_grad_sizes, net._fdgs_grad_shapes
+            if self._dflat is None or self._dflat[0].device != g._xyz.device:
+                flat = torch.empty(sum(sizes), device=g._xyz.device, dtype=torch.float32)
+                dgrads = [None] * len(params)
+                for i, piece, shape in zip(order, flat.split_with_sizes(sizes), shapes):
+                    dgrads[i] = piece.view(shape)
+                self._dflat = (flat, dgrads)
+            flat, dgrads = self._dflat
+            flat.zero_()
+        loss = psnr_sum = radii = None
+        acc = None
+        for i, cam in enumerate(views):
+            vg = self.pipeline.run(cam, cam.original_image, scale, self.stage, grad_set=min(i, 1), deform_grads=dgrads,
+                                   sh_hook=hook if fine else None)
+            loss = vg.loss.clone() if loss is None else loss + vg.loss
+            psnr_sum = vg.psnr.clone() if psnr_sum is None else psnr_sum + vg.psnr
+            if i == 0:
+                acc = vg
+                radii = vg.radii if len(views) == 1 else vg.radii.clone()
+            else:
+                torch._foreach_add_([acc.xyz, acc.scaling, acc.rotation, acc.opacity, acc.shs, acc.means2D],
+                                    [vg.xyz, vg.scaling, vg.rotation, vg.opacity, vg.shs, vg.means2D])
+                radii = torch.maximum(radii, vg.radii)
+        self.last_psnr = psnr_sum / len(views) if len(views) > 1 else psnr_sum
+        g._xyz.grad, g._scaling.grad, g._rotation.grad, g._opacity.grad = acc.xyz, acc.scaling, acc.rotation, acc.opacity
+        g._features_dc.grad, g._features_rest.grad = acc.shs[:, :1, :], acc.shs[:, 1:, :]
+        if fine:
+            for p, gr in zip(params, dgrads):
+                p.grad = gr
+        return loss, radii, radii > 0, acc.means2D
+
+    def _views_autograd(self, views, scale, hook):
+        """render() + autograd: the reference's interface (any activation callables, SSIM term)."""
+        radii_list, vis_list, vsp_list = [], [], []
+        loss = None
+        psnr_sum = None
+        for cam in views:
+            pkg = render(cam, self.g, self.deforms, self.bg, stage=self.stage, cam_type="dynerf")
+            # loss and the iteration's PSNR (fdgs_trainer.py:130-131) from one pass over the two images
+            l1, view_psnr = losses.l1_loss_psnr(pkg["render"], cam.original_image, scale)
+            psnr_sum = view_psnr if psnr_sum is None else psnr_sum + view_psnr
+            loss = l1 if loss is None else loss + l1
+            if self.lambda_dssim != 0:      # fdgs_trainer.py:136-138; the mean over the batch is the mean of the views'
+                loss = loss + (self.lambda_dssim * scale) * (1.0 - losses.ssim(pkg["render"], cam.original_image))
+            radii_list.append(pkg["radii"])
+            vis_list.append(pkg["visibility_filter"])
+            vsp_list.append(pkg["viewspace_points"])
+        self.last_psnr = psnr_sum / len(views) if (psnr_sum is not None and len(views) > 1) else psnr_sum
+        if loss is None:
+            return None, None, None, None
+        from . import deformation
+        deformation.RESIDUAL_GRAD_HOOK = hook
+        try:
+            loss.backward()
+        finally:
+            deformation.RESIDUAL_GRAD_HOOK = None
+        if len(views) == 1:
+            return loss, radii_list[0], vis_list[0], vsp_list[0].grad
+        radii = torch.stack(radii_list, 0).max(dim=0).values
+        vis = torch.stack(vis_list, 0).any(dim=0)
+        vgrad = torch.zeros_like(vsp_list[0])
+        for v in vsp_list:
+            vgrad = vgrad + v.grad
+        return loss, radii, vis, vgrad
+
     @property
     def regulation(self):
         return self.regulation_weights if "fine" in self.stage else None
@@ -111,21 +194,8 @@ class TrainStep:
             self.learning_rates.update(self.optimizer, iteration)
         views = dp.shard_views(global_views)
         scale = dp.local_loss_scale(len(views), len(global_views))
-        radii_list, vis_list, vsp_list = [], [], []
-        loss = None
-        psnr_sum = None
-        for cam in views:
-            pkg = render(cam, self.g, self.deforms, self.bg, stage=self.stage, cam_type="dynerf")
-            # loss and the iteration's PSNR (fdgs_trainer.py:130-131) from one pass over the two images
-            l1, view_psnr = losses.l1_loss_psnr(pkg["render"], cam.original_image, scale)
-            psnr_sum = view_psnr if psnr_sum is None else psnr_sum + view_psnr
-            loss = l1 if loss is None else loss + l1
-            if self.lambda_dssim != 0:      # fdgs_trainer.py:136-138; the mean over the batch is the mean of the views'
-                loss = loss + (self.lambda_dssim * scale) * (1.0 - losses.ssim(pkg["render"], cam.original_image))
-            radii_list.append(pkg["radii"])
-            vis_list.append(pkg["visibility_filter"])
-            vsp_list.append(pkg["viewspace_points"])
-        self.last_psnr = psnr_sum / len(views) if (psnr_sum is not None and len(views) > 1) else psnr_sum
+        n = self.g._xyz.shape[0]
+        dev = self.g._xyz.device
         # fdgs_trainer.py:133-135.  A view-independent term: every rank takes 1/world of it and the gradient
         # all-reduce (a sum) completes it.
         reg = None
@@ -134,38 +204,28 @@ class TrainStep:
             share = 1.0 / dp.rank_world()[1]
             reg_w = tuple(w * share for w in self.regulation)
         early = []
-        if loss is not None:
-            from . import deformation
-            # one view on every rank (so all ranks take this branch together): the view's SH gradient is the
-            # rank's whole contribution and can be exchanged while the deformation backward runs
-            if dp.is_dist() and len(global_views) == dp.rank_world()[1] and self.early_exchange:
-                def hook(g_sh):
-                    try:
-                        work = dp.all_reduce_async(g_sh)
-                    except Exception:       # the collective could not be started (the same on every rank): the
-                        self.early_exchange = False     # gradient then travels with the bucket, now and later
-                        return None
-                    early.append(g_sh)
-                    return work
-                deformation.RESIDUAL_GRAD_HOOK = hook
-            try:
-                loss.backward()
-            finally:
-                deformation.RESIDUAL_GRAD_HOOK = None
+        hook = None
+        # one view on every rank (so all ranks take this branch together): the view's SH gradient is the
+        # rank's whole contribution and can be exchanged while the deformation backward runs
+        if views and dp.is_dist() and len(global_views) == dp.rank_world()[1] and self.early_exchange:
+            def hook(g_sh):
+                try:
+                    work = dp.all_reduce_async(g_sh)
+                except Exception:       # the collective could not be started (the same on every rank): the
+                    self.early_exchange = False     # gradient then travels with the bucket, now and later
+                    return None
+                early.append(g_sh)
+                return work
+        direct = (self.use_pipeline and self.lambda_dssim == 0 and self.pipeline.usable(self.stage)
+                  and all(getattr(c, "original_image", None) is not None for c in views))
+        if direct:
+            loss, radii, vis, vgrad = self._views_direct(views, scale, hook)
+        else:
+            loss, radii, vis, vgrad = self._views_autograd(views, scale, hook)
         if reg_w is not None:
             # same gradients as adding the term to the loss, written into the planes' .grad in one launch
             reg = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
-        n = self.g._xyz.shape[0]
-        dev = self.g._xyz.device
-        if len(views) == 1:
-            radii, vis, vgrad = radii_list[0], vis_list[0], vsp_list[0].grad
-        elif views:
-            radii = torch.stack(radii_list, 0).max(dim=0).values
-            vis = torch.stack(vis_list, 0).any(dim=0)
-            vgrad = torch.zeros_like(vsp_list[0])
-            for v in vsp_list:
-                vgrad = vgrad + v.grad
-        else:   # a rank without views this step still takes part in the collectives, with zeros for exactly the
+        if not views:   # a rank without views this step still takes part in the collectives, with zeros for exactly the
             # tensors that get a gradient in this stage on the other ranks (the deformation field: fine stage only)
             radii = torch.zeros(n, dtype=torch.int32, device=dev)
             vis = torch.zeros(n, dtype=torch.bool, device=dev)
