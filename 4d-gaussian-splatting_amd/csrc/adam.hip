@@ -35,6 +35,44 @@ adam_kernel(AdamK k) {
     const long long n = k.a.numel[t];
     const float o1 = k.omb1, b2 = (float)k.a.beta2, o2 = k.omb2, eps = (float)k.a.eps, ss = k.step_size[t], ib = k.inv_sqrt_bc2[t];
     const long long base = (long long)((int)blockIdx.x - k.block_start[t]) * ADAM_PER_BLOCK;
+    const int L = k.a.grad_row_len[t];
+    if (L > 0) {
+        // the gradient is a column slice of a wider array (row length L, row stride S): read element by element;
+        // parameter and moments stay contiguous (16-byte accesses when aligned)
+        const long long S = k.a.grad_row_stride[t];
+        const bool vec3 = ((((size_t)p | (size_t)m | (size_t)v) & 15) == 0) && base + ADAM_PER_BLOCK <= n;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long i = base + 4 * (threadIdx.x + 256 * u);
+            if (i >= n) break;
+            long long row = i / L;
+            int col = (int)(i - row * L);
+            float gv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gv[j] = (i + j < n) ? g[row * S + col] : 0.0f;
+                if (++col == L) { col = 0; ++row; }
+            }
+            if (vec3) {
+                float4 pp = *reinterpret_cast<float4*>(p + i);
+                float4 mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+                adam_one(pp.x, gv[0], mm.x, vv.x, o1, b2, o2, eps, ss, ib);
+                adam_one(pp.y, gv[1], mm.y, vv.y, o1, b2, o2, eps, ss, ib);
+                adam_one(pp.z, gv[2], mm.z, vv.z, o1, b2, o2, eps, ss, ib);
+                adam_one(pp.w, gv[3], mm.w, vv.w, o1, b2, o2, eps, ss, ib);
+                *reinterpret_cast<float4*>(p + i) = pp;
+                *reinterpret_cast<float4*>(m + i) = mm;
+                *reinterpret_cast<float4*>(v + i) = vv;
+            } else {
+                for (int j = 0; j < 4 && i + j < n; ++j) {
+                    float pp = p[i + j], mm = m[i + j], vv = v[i + j];
+                    adam_one(pp, gv[j], mm, vv, o1, b2, o2, eps, ss, ib);
+                    p[i + j] = pp; m[i + j] = mm; v[i + j] = vv;
+                }
+            }
+        }
+        return;
+    }
     const bool vec = ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0);
     if (vec && base + ADAM_PER_BLOCK <= n) {
 #pragma unroll
@@ -71,7 +109,8 @@ extern "C" int fdgs_adam_step(const fdgs_adam_args* a, void* stream) {
     for (int t = 0; t < a->num_tensors; ++t) {
         if (a->numel[t] < 0) return FDGS_EINVAL;
         if (a->numel[t] > 0 && (!a->param[t] || !a->grad[t] || !a->exp_avg[t] || !a->exp_avg_sq[t])) return FDGS_EINVAL;
-        if (a->step[t] < 1) return FDGS_EINVAL;
+        if (a->step[t] < 1 || a->grad_row_len[t] < 0) return FDGS_EINVAL;
+        if (a->grad_row_len[t] > 0 && a->grad_row_stride[t] < a->grad_row_len[t]) return FDGS_EINVAL;
         const double bc1 = 1.0 - pow(a->beta1, (double)a->step[t]);
         const double bc2 = 1.0 - pow(a->beta2, (double)a->step[t]);
         k.block_start[t] = (int)blocks;

@@ -304,6 +304,7 @@ struct DeformFwdK {
     const float* pw0; const float* b0;              // packed first Linear
     const float* pw1[5]; const float* b1[5]; const float* pw2[5]; const float* b2[5];
     const float* xyz; const float* in[5];           // in[0] = xyz ... in[4] = shs (residual inputs)
+    const float* in_rest;                           // NULL, or in[4] is f_dc [n,3] and this is f_rest [n,45]
     const float* time; float time_scalar;
     float* out[5];
     float* save_hidden;
@@ -363,7 +364,9 @@ deform_fwd_kernel(DeformFwdK a) {
                     for (int q = 0; q < 4; ++q) {
                         const int row = 32 * ob + 8 * q + 4 * h;
                         if (row < k) {
-                            const float4 iv = *reinterpret_cast<const float4*>(in + (size_t)p * k + row);
+                            const bool two = head == 4 && a.in_rest != nullptr;
+                            const float4 iv = fdgs_load_sh4(two ? a.in_rest + (size_t)p * 45 - 3 : in + (size_t)p * k,
+                                                            two ? in + (size_t)p * 3 : nullptr, row);
                             *reinterpret_cast<float4*>(out + (size_t)p * k + row) =
                                 make_float4(iv.x + o[4 * q], iv.y + o[4 * q + 1], iv.z + o[4 * q + 2], iv.w + o[4 * q + 3]);
                         }
@@ -614,6 +617,7 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     g.feat_split = feat; g.feat_f32 = nullptr; g.feat_y = reinterpret_cast<u32x4*>(a->save_yfeat);
     k.feat_split = feat;
     k.in[0] = a->xyz; k.in[1] = a->scales; k.in[2] = a->rotations; k.in[3] = a->opacity; k.in[4] = a->shs;
+    k.in_rest = a->shs_rest;
     k.out[0] = a->out_xyz; k.out[1] = a->out_scales; k.out[2] = a->out_rotations; k.out[3] = a->out_opacity;
     k.out[4] = a->out_shs;
     for (int h = 0; h < 5; ++h) { k.w2[h] = a->p.w2[h]; k.b2[h] = a->p.b2[h]; }
@@ -698,6 +702,7 @@ extern "C" int fdgs_deform_fwd(const fdgs_deform_fwd_args* a, void* stream) {
     for (int h = 0; h < 5; ++h) { k.b1[h] = a->p.b1[h]; k.b2[h] = a->p.b2[h]; }
     k.xyz = a->xyz;
     k.in[0] = a->xyz; k.in[1] = a->scales; k.in[2] = a->rotations; k.in[3] = a->opacity; k.in[4] = a->shs;
+    k.in_rest = a->shs_rest;
     k.out[0] = a->out_xyz; k.out[1] = a->out_scales; k.out[2] = a->out_rotations; k.out[3] = a->out_opacity;
     k.out[4] = a->out_shs;
     k.time = a->time; k.time_scalar = a->time_scalar;

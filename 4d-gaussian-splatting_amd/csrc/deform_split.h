@@ -441,6 +441,7 @@ struct DeformFwdSK {
     const u32x4* pw1[5]; const float* pb1[5]; const u32x4* pw2[5]; const float* pb2[5];
     const float* w2[5]; const float* b2[5];          // unpacked output layers (used for the heads with k <= 4)
     const float* in[5];                              // residual inputs: xyz, scales, rotations, opacity, shs
+    const float* in_rest;                            // NULL, or in[4] is f_dc [n,3] and this is f_rest [n,45]
     float* out[5];
     float* save_hidden;                              // optional [n,128]: hidden, pre-activation
     u32x4* save_act;                                 // relu(hidden) as split operand pieces: [ceil(n/32)][8][3][64]
@@ -612,12 +613,14 @@ deform_fwd_split_kernel(DeformFwdSK a) {
 #pragma unroll
             for (int cb = 0; cb < SCB; ++cb) {
                 const int p = min(base + 32 * cb + c, a.n - 1);
+                const float* __restrict__ row0 = a.in_rest ? a.in_rest + (size_t)p * 45 - 3 : in + (size_t)p * k;
+                const float* __restrict__ dc = a.in_rest ? in + (size_t)p * 3 : nullptr;
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const int row = 32 * ob + 8 * q + 4 * h;
-                        iv[cb][ob][q] = row < k ? *reinterpret_cast<const float4*>(in + (size_t)p * k + row)
+                        iv[cb][ob][q] = row < k ? fdgs_load_sh4(row0, (ob == 0 && q == 0) ? dc : nullptr, row)
                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     }
             }

@@ -119,3 +119,15 @@ __device__ __forceinline__ bool fdgs_reaches(float gx, float gy, uint32_t reach,
     const float hy = __half2float(__ushort_as_half((unsigned short)(reach >> 16)));
     return (gx + hx >= rx0) && (gx - hx <= rx1) && (gy + hy >= ry0) && (gy - hy <= ry1);
 }
+
+// Four consecutive SH floats [row, row + 4) of a point, row a multiple of 4.  `base` is the point's row in one
+// [N,16,3] array (dc == nullptr), or (rest + 45 p - 3) when the coefficients come as the two tensors the reference's
+// GaussianModel keeps (src/model/gaussian_model.py:64-65,86-89: dc [N,1,3] and rest [N,15,3], whose concatenation
+// along the coefficient axis is the [N,16,3] array): floats 3-47 of the row are then rest's 45 floats, read with
+// 4-byte alignment, and floats 0-2 come from dc + 3 p.
+struct __attribute__((packed, aligned(4))) fdgs_f4u { float x, y, z, w; };
+__device__ __forceinline__ float4 fdgs_load_sh4(const float* __restrict__ base, const float* __restrict__ dc, int row) {
+    if (dc != nullptr && row == 0) return make_float4(dc[0], dc[1], dc[2], base[3]);
+    const fdgs_f4u v = *reinterpret_cast<const fdgs_f4u*>(base + row);
+    return make_float4(v.x, v.y, v.z, v.w);
+}

@@ -34,6 +34,10 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
         }
     } else {
         const float4 d0 = dg4[0], d1 = dg4[1], d2 = dg4[2];
+        if (a.clear_dL_dgeom && inb) {               // only splats with a radius are ever accumulated into
+            float4* z = const_cast<float4*>(dg4);
+            z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         const float g_px = d0.x, g_py = d0.y, gA = d0.z, gB = d0.w, gC = d1.x;
         dop = d1.y;
         float gcol[3] = {d1.z, d1.w, d2.x};

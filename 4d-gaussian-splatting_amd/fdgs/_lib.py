@@ -61,7 +61,7 @@ class PreprocessBwdArgs(C.Structure):
                 ("geom", c_p), ("dL_dgeom", c_p),
                 ("dL_dmeans3D", c_p), ("dL_dmeans2D", c_p), ("dL_dscales", c_p), ("dL_drotations", c_p),
                 ("dL_dopacities", c_p), ("dL_dshs", c_p), ("dL_dcolors", c_p), ("dL_dcov3D", c_p),
-                ("activations", c_i32)]
+                ("activations", c_i32), ("clear_dL_dgeom", c_i32)]
 
 
 L1_STATIC_MAX_N = 16384 * 4096          # FDGS_L1_STATIC_MAX_N
@@ -89,7 +89,7 @@ class DeformFwdArgs(C.Structure):
                 ("xyz", c_p), ("scales", c_p), ("rotations", c_p), ("opacity", c_p), ("shs", c_p),
                 ("time", c_p), ("time_scalar", c_f),
                 ("out_xyz", c_p), ("out_scales", c_p), ("out_rotations", c_p), ("out_opacity", c_p),
-                ("out_shs", c_p), ("save_hidden", c_p), ("save_act", c_p), ("save_mask", c_p), ("save_yhid", c_p), ("save_yfeat", c_p), ("workspace", c_p), ("workspace_bytes", c_sz)]
+                ("out_shs", c_p), ("save_hidden", c_p), ("save_act", c_p), ("save_mask", c_p), ("save_yhid", c_p), ("save_yfeat", c_p), ("workspace", c_p), ("workspace_bytes", c_sz), ("shs_rest", c_p)]
 
 
 class DeformBwdArgs(C.Structure):
@@ -183,7 +183,8 @@ class AdamArgs(C.Structure):
     _fields_ = [("num_tensors", c_i32), ("step", c_i32 * ADAM_MAX_TENSORS), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
                 ("lr", c_f * ADAM_MAX_TENSORS), ("numel", c_i64 * ADAM_MAX_TENSORS),
                 ("param", c_p * ADAM_MAX_TENSORS), ("grad", c_p * ADAM_MAX_TENSORS),
-                ("exp_avg", c_p * ADAM_MAX_TENSORS), ("exp_avg_sq", c_p * ADAM_MAX_TENSORS)]
+                ("exp_avg", c_p * ADAM_MAX_TENSORS), ("exp_avg_sq", c_p * ADAM_MAX_TENSORS),
+                ("grad_row_len", c_i32 * ADAM_MAX_TENSORS), ("grad_row_stride", c_i64 * ADAM_MAX_TENSORS)]
 
 
 # every symbol include/fdgs.h declares: name -> (restype, argtypes)
@@ -224,7 +225,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 def _load():

@@ -20,6 +20,19 @@ from . import _lib
 GENERATION = [0]
 
 
+def _row_slice(t):
+    """(row length, row stride) when `t` [rows, ...] is a column slice of a wider row-major array - every row a
+    contiguous run of elements, rows a constant stride apart - else None."""
+    if t.dim() < 2 or t.shape[0] == 0:
+        return None
+    inner = t[0]
+    if not inner.is_contiguous():
+        return None
+    length = inner.numel()
+    stride = t.stride(0)
+    return (length, stride) if stride >= length > 0 else None
+
+
 class FusedAdam:
     def __init__(self, params, lr=0.0, betas=(0.9, 0.999), eps=1e-8):
         self.param_groups = []
@@ -63,13 +76,17 @@ class FusedAdam:
                           "exp_avg": torch.zeros_like(p, memory_format=torch.contiguous_format),
                           "exp_avg_sq": torch.zeros_like(p, memory_format=torch.contiguous_format)}
                     self.state[p] = st
-                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                grad, row = p.grad, None
+                if not grad.is_contiguous():
+                    row = _row_slice(grad)          # a column slice of a wider array is read in place
+                    if row is None:
+                        grad = grad.contiguous()
                 if not (p.is_cuda and grad.is_cuda):
                     raise RuntimeError("libfdgs kernels run on the GPU only")
                 if not p.is_contiguous() or p.dtype is not torch.float32 or grad.dtype is not torch.float32:
                     raise ValueError("FusedAdam needs contiguous float32 parameters and gradients")
                 st["step"] = int(st.get("step", 0)) + 1
-                entries.append((p, grad, st, float(g["lr"])))
+                entries.append((p, grad, st, float(g["lr"]), row))
         if not entries:
             return
         b1, b2 = self.param_groups[0]["betas"]
@@ -79,8 +96,10 @@ class FusedAdam:
             a = _lib.AdamArgs()
             a.num_tensors, a.beta1, a.beta2, a.eps = len(part), b1, b2, eps
             steps, lrs, numels, pp, gp, mp, vp = a.step, a.lr, a.numel, a.param, a.grad, a.exp_avg, a.exp_avg_sq
-            for t, (p, grad, st, lr) in enumerate(part):
+            for t, (p, grad, st, lr, row) in enumerate(part):
                 steps[t] = st["step"]; lrs[t] = lr; numels[t] = p.numel()
+                if row is not None:
+                    a.grad_row_len[t], a.grad_row_stride[t] = row
                 pp[t] = p.data_ptr(); gp[t] = grad.data_ptr()
                 mp[t] = st["exp_avg"].data_ptr(); vp[t] = st["exp_avg_sq"].data_ptr()
             _lib.call("fdgs_adam_step", a)

@@ -116,7 +116,9 @@ class ViewPipeline:
         fine = "fine" in stage
         S = self.sets[grad_set]
         sc, ro, op = g._scaling.detach(), g._rotation.detach(), g._opacity.detach()
-        torch.cat((g._features_dc.detach(), g._features_rest.detach()), dim=1, out=self.shs_in)
+        f_dc, f_rest = g._features_dc.detach(), g._features_rest.detach()
+        if not fine:        # the rasterizer reads one [N,16,3] array; the deformation field reads the two tensors
+            torch.cat((f_dc, f_rest), dim=1, out=self.shs_in)
         tanx, tany = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         vm = cam.world_view_transform
         pm = cam.full_proj_transform
@@ -131,11 +133,11 @@ class ViewPipeline:
                 self.hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32)
             fws, fws_bytes, bws, bws_bytes = self._deform_buffers(P, N, dev)
             o = self.d_out
-            a = _lib.DeformFwdArgs(N, P, ptr(xyz), ptr(sc), ptr(ro), ptr(op), ptr(self.shs_in), None, float(cam.time),
+            a = _lib.DeformFwdArgs(N, P, ptr(xyz), ptr(sc), ptr(ro), ptr(op), ptr(f_dc), None, float(cam.time),
                                    ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), ptr(o[4]),
                                    None if split else ptr(self.hidden), ptr(self.act) if split else None,
                                    ptr(self.mask) if split else None, ptr(self.yhid) if split else None,
-                                   ptr(self.yfeat) if split else None, ptr(fws), fws_bytes)
+                                   ptr(self.yfeat) if split else None, ptr(fws), fws_bytes, ptr(f_rest))
             _lib.call("fdgs_deform_fwd", a)
             m3, scales, rots, opac, shs = o[0], o[1], o[2], o[3].reshape(-1), o[4]
         else:
@@ -166,8 +168,7 @@ class ViewPipeline:
                                                      ptr(self.l1_partial), ptr(self.psnr) if want_psnr else None))
         _lib.call("fdgs_l1_loss_bwd", _lib.L1BwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(self._one),
                                                      ptr(self.grad_image)))
-        self.dgeom.zero_()
-        _lib.call("fdgs_raster_blend_bwd",
+        _lib.call("fdgs_raster_blend_bwd",      # dgeom: zero from its allocation, re-zeroed by preprocess_bwd below
                   _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),
                                     ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom)))
         d_m3 = S["means3D"] if fine else S["xyz"]
@@ -175,7 +176,7 @@ class ViewPipeline:
                   _lib.PreprocessBwdArgs(N, sh_degree, W, H, tanx, tany, 1.0, ptr(vm), ptr(pm), ptr(cp), ptr(m3),
                                          ptr(scales), ptr(rots), ptr(shs), None, None, ptr(self.geom), ptr(self.dgeom),
                                          ptr(d_m3), ptr(S["means2D"]), ptr(S["scaling"]), ptr(S["rotation"]),
-                                         ptr(S["opacity"]), ptr(S["shs"]), None, None, acts))
+                                         ptr(S["opacity"]), ptr(S["shs"]), None, None, acts, 1))
         out = ViewGrads()
         g_sh = S["shs"]
         pending = None

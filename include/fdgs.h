@@ -183,6 +183,9 @@ typedef struct {
     float* dL_dcolors;               /* [N,3]      (colors_precomp path)            */
     float* dL_dcov3D;                /* [N,6]      (cov3D_precomp path)             */
     int32_t activations;             /* as in the forward call; the gradients are then w.r.t. the raw tensors */
+    int32_t clear_dL_dgeom;          /* non-zero: every record of dL_dgeom that was read is written back as zeros, so a
+                                        buffer the caller keeps is ready for the next fdgs_raster_blend_bwd (which
+                                        accumulates into it) without a fill in between                          */
 } fdgs_preprocess_bwd_args;
 
 int fdgs_raster_preprocess_bwd(const fdgs_preprocess_bwd_args* a, void* stream);
@@ -253,6 +256,10 @@ typedef struct {
     void* save_yfeat;
     void* workspace;                 /* fdgs_deform_fwd_workspace_bytes(&p, N) bytes */
     size_t workspace_bytes;
+    /* NULL, or the SH coefficients come as the two tensors GaussianModel keeps (src/model/gaussian_model.py:64-65):
+     * `shs` is then _features_dc [N,1,3] and shs_rest is _features_rest [N,15,3]; their concatenation
+     * (get_features, :86-89) is never materialised.  out_shs stays one [N,16,3] array.                    */
+    const float* shs_rest;
 } fdgs_deform_fwd_args;
 
 size_t fdgs_deform_fwd_workspace_bytes(const fdgs_deform_params* p, int32_t num_points);
@@ -403,6 +410,12 @@ typedef struct {
     const float* grad[FDGS_ADAM_MAX_TENSORS];
     float* exp_avg[FDGS_ADAM_MAX_TENSORS];
     float* exp_avg_sq[FDGS_ADAM_MAX_TENSORS];
+    /* 0: grad[t] is contiguous like the parameter.  L > 0: the gradient of tensor t is a column slice of a wider
+     * row-major array - element e of the tensor is grad[t][(e / L) * grad_row_stride[t] + e % L] (the gradients of
+     * _features_dc [N,1,3] and _features_rest [N,15,3] are the slices [:, :3] and [:, 3:] of dL/dSH [N,48]: L = 3
+     * or 45, stride 48, and no copy of either is made)                                                    */
+    int32_t grad_row_len[FDGS_ADAM_MAX_TENSORS];
+    int64_t grad_row_stride[FDGS_ADAM_MAX_TENSORS];
 } fdgs_adam_args;
 
 int fdgs_adam_step(const fdgs_adam_args* a, void* stream);

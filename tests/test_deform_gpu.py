@@ -216,3 +216,34 @@ def test_two_backward_calls_on_two_streams_overlap_safely():
     for ref, got in ((ref_a, got_a), (ref_b, got_b)):
         for r, g in zip(ref, got):
             assert float((r - g).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-12     # atomics: order noise only
+
+
+@pytest.mark.parametrize("n", [1, 333, 4097])
+def test_forward_reads_the_two_sh_tensors_without_a_concatenation(matmul, n):
+    """fdgs_deform_fwd_args.shs_rest: the SH coefficients as GaussianModel keeps them, _features_dc [N,1,3] and
+    _features_rest [N,15,3], instead of their concatenation: all five outputs bit-identical."""
+    import ctypes as C
+    from fdgs import _lib, deformation
+    from fdgs._lib import lib, ptr
+    dev = torch.device("cuda:0")
+    net, _ = _module("dynerf", dev)
+    gen = torch.Generator().manual_seed(41)
+    xyz = (3.0 * torch.rand(n, 3, generator=gen) - 1.5).to(dev)
+    sc, ro, op = (torch.randn(n, k, generator=gen).to(dev) for k in (3, 4, 1))
+    f_dc, f_rest = torch.randn(n, 1, 3, generator=gen).to(dev), torch.randn(n, 15, 3, generator=gen).to(dev)
+    shs = torch.cat((f_dc, f_rest), dim=1).contiguous()
+    P = deformation._fill_params(net.deformation_net)
+    ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), n)
+    outs = []
+    for dc_arg, rest_arg in ((shs, None), (f_dc, f_rest)):
+        ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
+        o = [torch.empty(n, k, device=dev) for k in (3, 3, 4, 1, 48)]
+        a = _lib.DeformFwdArgs(n, P, ptr(xyz), ptr(sc), ptr(ro), ptr(op), ptr(dc_arg), None, 0.37,
+                               ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(o[3]), ptr(o[4]), None, None, None, None, None,
+                               ptr(ws), ws_bytes, ptr(rest_arg))
+        _lib.call("fdgs_deform_fwd", a)
+        outs.append(o)
+    torch.cuda.synchronize()
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+    assert float((outs[0][4] - shs.reshape(n, 48)).abs().max()) > 0       # the head's residual was added

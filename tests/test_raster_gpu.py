@@ -271,6 +271,39 @@ def test_fused_adam_counts_steps_per_tensor_and_round_trips_its_state():
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max()))
 
 
+def test_fused_adam_reads_column_slice_gradients_in_place():
+    """The gradients of _features_dc [N,1,3] and _features_rest [N,15,3] are the column slices [:, :1] and [:, 1:]
+    of one dL/dSH [N,16,3] array: FusedAdam reads them where they are (fdgs_adam_args.grad_row_len / _stride)
+    and must give what torch.optim.Adam gives on contiguous copies.  N is odd-sized so that rows straddle the
+    kernel's four-element groups and its last workgroup is partial."""
+    from fdgs.adam import FusedAdam
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(13)
+    n = 10007
+    dc0, rest0 = torch.randn(n, 1, 3, generator=gen).to(dev), torch.randn(n, 15, 3, generator=gen).to(dev)
+    ref_p = [dc0.clone().requires_grad_(True), rest0.clone().requires_grad_(True)]
+    our_p = [dc0.clone().requires_grad_(True), rest0.clone().requires_grad_(True)]
+    lrs = [2.5e-3, 2.5e-3 / 20]
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(ref_p, lrs)], lr=0.0, eps=1e-15)
+    our = FusedAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(our_p, lrs))],
+                    lr=0.0, eps=1e-15)
+    for step in range(3):
+        g_sh = torch.randn(n, 16, 3, generator=gen).to(dev)
+        ref_p[0].grad, ref_p[1].grad = g_sh[:, :1, :].contiguous(), g_sh[:, 1:, :].contiguous()
+        our_p[0].grad, our_p[1].grad = g_sh[:, :1, :], g_sh[:, 1:, :]
+        assert not our_p[1].grad.is_contiguous()
+        keep = g_sh.clone()
+        ref.step()
+        our.step()
+        assert torch.equal(g_sh, keep)                      # read in place, never written
+    torch.cuda.synchronize()
+    for a, b in zip(ref_p, our_p):
+        assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max()))
+        for key in ("exp_avg", "exp_avg_sq"):
+            x, y = ref.state[a][key], our.state[b][key]
+            assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max()), key
+
+
 def test_l1_loss_and_densification_stats_match_torch():
     """fdgs.losses: scale * mean|a - b| with its gradient (src/model/losses.py:7-8) and the statistics update of
     src/runner/fdgs_trainer.py:181-182 against the PyTorch expressions; sizes that exercise the 16-byte path,
