@@ -101,11 +101,14 @@ class ViewPipeline:
 
     # ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def run(self, cam, gt, scale, stage, grad_set=0, deform_grads=None, want_psnr=True, sh_hook=None):
+    def run(self, cam, gt, scale, stage, grad_set=0, deform_grads=None, want_psnr=True, sh_hook=None,
+            while_waiting=None):
         """Forward, loss and backward of one view.  gt: [3,H,W] float32 on the device.  scale: the view's share of
         the batch loss (1 / views in the batch).  deform_grads: the 34 gradient tensors of the deformation field in
         the order of fdgs.deformation._trainable, accumulated into (fine stage).  Returns a ViewGrads whose tensors
-        are this object's buffers of set `grad_set` (valid until that set is used again)."""
+        are this object's buffers of set `grad_set` (valid until that set is used again).  while_waiting: callable
+        run after the tile-list length has been requested from the device and before the host waits for it - work
+        enqueued there (anything that does not depend on this view) runs while that 4-byte read is in flight."""
         g = self.g
         xyz = g._xyz.detach()
         dev = xyz.device
@@ -151,7 +154,11 @@ class ViewPipeline:
         _lib.call("fdgs_raster_preprocess_fwd", pa)
         # the data-dependent list length R: one 4-byte device->host read (the step's only synchronisation)
         self.r_host.copy_(self.point_offsets[N - 1:N], non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        ready = torch.cuda.Event()
+        ready.record()
+        if while_waiting is not None:
+            while_waiting()
+        ready.synchronize()
         R = int(self.r_host[0])
         _rasterizer.LAST_NUM_RENDERED = R
         self._list_buffers(max(R, 1), dev)

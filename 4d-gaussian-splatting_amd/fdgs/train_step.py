@@ -100,7 +100,7 @@ class TrainStep:
         self._bind_parameters()
 
     # -- the per-view work, two routes to the same gradients ---------------------------------------------------
-    def _views_direct(self, views, scale, hook):
+    def _views_direct(self, views, scale, hook, while_waiting=None):
         """fdgs/pipeline.py: the chain of C-ABI calls on persistent buffers; gradients attached to .grad here."""
         if not views:
             return None, None, None, None
@@ -120,11 +120,13 @@ class TrainStep:
                 self._dflat = (flat, dgrads)
             flat, dgrads = self._dflat
             flat.zero_()
+            for p, gr in zip(params, dgrads):     # attached now: the regulariser may add to them before the first
+                p.grad = gr                        # view's backward does
         loss = psnr_sum = radii = None
         acc = None
         for i, cam in enumerate(views):
             vg = self.pipeline.run(cam, cam.original_image, scale, self.stage, grad_set=min(i, 1), deform_grads=dgrads,
-                                   sh_hook=hook if fine else None)
+                                   sh_hook=hook if fine else None, while_waiting=while_waiting if i == 0 else None)
             loss = vg.loss.clone() if loss is None else loss + vg.loss
             psnr_sum = vg.psnr.clone() if psnr_sum is None else psnr_sum + vg.psnr
             if i == 0:
@@ -137,9 +139,6 @@ class TrainStep:
         self.last_psnr = psnr_sum / len(views) if len(views) > 1 else psnr_sum
         g._xyz.grad, g._scaling.grad, g._rotation.grad, g._opacity.grad = acc.xyz, acc.scaling, acc.rotation, acc.opacity
         g._features_dc.grad, g._features_rest.grad = acc.shs[:, :1, :], acc.shs[:, 1:, :]
-        if fine:
-            for p, gr in zip(params, dgrads):
-                p.grad = gr
         return loss, radii, radii > 0, acc.means2D
 
     def _views_autograd(self, views, scale, hook):
@@ -219,7 +218,16 @@ class TrainStep:
         direct = (self.use_pipeline and self.lambda_dssim == 0 and self.pipeline.usable(self.stage)
                   and all(getattr(c, "original_image", None) is not None for c in views))
         if direct:
-            loss, radii, vis, vgrad = self._views_direct(views, scale, hook)
+            # the regulariser depends on no view: it is enqueued inside the first view's forward, where the host
+            # waits for the tile-list length and the GPU would otherwise idle
+            box = {}
+
+            def regulariser():
+                if reg_w is not None:
+                    box["reg"] = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
+            loss, radii, vis, vgrad = self._views_direct(views, scale, hook, regulariser if views else None)
+            if "reg" in box:
+                reg, reg_w = box["reg"], None
         else:
             loss, radii, vis, vgrad = self._views_autograd(views, scale, hook)
         if reg_w is not None:
