@@ -76,6 +76,15 @@ __device__ __forceinline__ void sh_tile_copy(float* __restrict__ tile, float* __
     }
 }
 
+// The blend backward accumulates into dL_dgeom [N,12] in the scaling its inner loop works in (the conic is staged
+// multiplied by -log2(e)); preprocess_bwd multiplies by these constants when it reads the record:
+//   [0],[1]  sum g (a2 dx + b1 dy), sum g (c2 dy + b1 dx)  = log2(e) dL/d(x_pix, y_pix)
+//   [2],[3],[4]  sum g dx^2, sum g dx dy, sum g dy^2        = -2 dL/dA, -dL/dB, -2 dL/dC
+//   [5] dL/d(opacity)   [6],[7],[8] dL/d(r, g, b)           (g = dL/d(exponent) of the pixel-Gaussian pair)
+#define FDGS_DGEOM_XY 0.6931471805599453f
+#define FDGS_DGEOM_AC (-0.5f)
+#define FDGS_DGEOM_B (-1.0f)
+
 // Slots 10 and 11 of the packed per-Gaussian record.
 //   [10]: radius in bits 0-27, SH clamp mask in bits 28-30.
 //   [11]: half-widths (x in the low, y in the high 16 bits, fp16 rounded up) of the axis-aligned box around the

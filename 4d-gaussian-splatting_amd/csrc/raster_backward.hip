@@ -38,7 +38,8 @@ preprocess_bwd_kernel(fdgs_preprocess_bwd_args a) {
             float4* z = const_cast<float4*>(dg4);
             z[0] = z[1] = z[2] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const float g_px = d0.x, g_py = d0.y, gA = d0.z, gB = d0.w, gC = d1.x;
+        const float g_px = FDGS_DGEOM_XY * d0.x, g_py = FDGS_DGEOM_XY * d0.y;
+        const float gA = FDGS_DGEOM_AC * d0.z, gB = FDGS_DGEOM_B * d0.w, gC = FDGS_DGEOM_AC * d1.x;
         dop = d1.y;
         float gcol[3] = {d1.z, d1.w, d2.x};
         const int W = a.image_width, H = a.image_height;

@@ -1,51 +1,101 @@
 // Rasterizer stage 6 (front-to-back alpha blending) and stage 7 (its backward).
 //
-// gfx950 mapping: one 256-thread workgroup per 16x16 tile, but each of its four
-// wavefronts owns one 8x8 pixel quadrant and walks the tile's depth-sorted list
-// on its own, with no workgroup barrier.  A batch of 64 list entries is loaded
-// one per lane; every lane tests whether its entry's 1/255-alpha ellipse can
-// reach the wave's quadrant, a 64-bit ballot collects the survivors and the wave
-// iterates over the set bits in list order.  The survivor's record reaches all lanes
-// through a wave-private LDS copy of the batch (three 16-byte stores per lane per batch,
-// same-address reads per survivor; other waves of the SIMD cover the read's latency - issuing
-// the next survivor's reads ahead cost more in register copies than it hid): both kernels are bound by vector-instruction issue, a v_readlane
-// per field is a vector instruction and an LDS read is not.  No workgroup barrier: a
-// wave's LDS instructions execute in program order.  Entries that cannot reach the
-// quadrant cost nothing; a quadrant stops as soon as its 64 pixels are saturated.
+// gfx950 mapping: one 256-thread workgroup per 16x16 tile; each of its four wavefronts owns one 8x8 pixel quadrant
+// and walks the tile's depth-sorted list on its own, with no workgroup barrier.  Inside the wave, each of the four
+// 16-lane DPP rows owns one 4x4 pixel block and walks ITS OWN list of survivors: a batch of 64 list entries is loaded
+// one per lane, every lane tests its entry's 1/255-alpha box against the four blocks, four 64-bit ballots collect the
+// survivors per block, and in every step each row takes the next survivor of its own block.  Splats here cover a
+// third of an 8x8 quadrant on average: with one survivor per wave and step two thirds of the lanes computed nothing.
+// A survivor's record reaches its row through a wave-private LDS copy of the batch (same-address reads within a
+// row; an LDS read is not a vector instruction, and both kernels are bound by vector-instruction issue).  A row
+// whose list is exhausted reads a null record (opacity 0: never contributes).  No workgroup barrier: a wave's LDS
+// instructions execute in program order.
+//
+// The conic is staged pre-scaled, a2 = -log2(e) A, b1 = -log2(e) B, c2 = -log2(e) C, so that
+// exp(power) = exp2(dx (a2 dx / 2 + b1 dy) + c2 dy^2 / 2) needs no further constant, and the backward accumulates
+// its five geometric sums in that scaling (fdgs_common.h: FDGS_DGEOM_*); preprocess_bwd applies the constants.
 #include "fdgs_common.h"
 
-#define BL_REC 2                                   // float4 per staged record: (x y A B) (C o r g); + one float2
+#define BL_SLOTS 65                                // 64 entries of a batch + the null record
+#define BL_NULL 64
 
 __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+
+// Turns the four survivor masks of a batch into four compacted lists of batch positions in the wave's LDS area
+// (list g, slot k = the k-th set bit of mask g): the inner loop then finds a row's next survivor with one LDS byte
+// read instead of scalar bit scans on four 64-bit masks (the scalar unit is shared by the CU's four SIMDs and was
+// the bottleneck with them).  Returns the longest list's length; `mine` = the length of this lane's row's list.
+__device__ __forceinline__ int build_lists(unsigned char* __restrict__ lists, unsigned long long m0,
+                                           unsigned long long m1, unsigned long long m2, unsigned long long m3,
+                                           int lane, int row, int& mine) {
+    const uint32_t lo0 = (uint32_t)m0, hi0 = (uint32_t)(m0 >> 32), lo1 = (uint32_t)m1, hi1 = (uint32_t)(m1 >> 32);
+    const uint32_t lo2 = (uint32_t)m2, hi2 = (uint32_t)(m2 >> 32), lo3 = (uint32_t)m3, hi3 = (uint32_t)(m3 >> 32);
+    const uint32_t r0 = __builtin_amdgcn_mbcnt_hi(hi0, __builtin_amdgcn_mbcnt_lo(lo0, 0u));   // set bits below this lane
+    const uint32_t r1 = __builtin_amdgcn_mbcnt_hi(hi1, __builtin_amdgcn_mbcnt_lo(lo1, 0u));
+    const uint32_t r2 = __builtin_amdgcn_mbcnt_hi(hi2, __builtin_amdgcn_mbcnt_lo(lo2, 0u));
+    const uint32_t r3 = __builtin_amdgcn_mbcnt_hi(hi3, __builtin_amdgcn_mbcnt_lo(lo3, 0u));
+    if ((m0 >> lane) & 1ull) lists[r0] = (unsigned char)lane;
+    if ((m1 >> lane) & 1ull) lists[64 + r1] = (unsigned char)lane;
+    if ((m2 >> lane) & 1ull) lists[128 + r2] = (unsigned char)lane;
+    if ((m3 >> lane) & 1ull) lists[192 + r3] = (unsigned char)lane;
+    const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
+    const uint32_t packed = (uint32_t)(n0 | (n1 << 8) | (n2 << 16) | (n3 << 24));
+    mine = (int)((packed >> (8 * row)) & 0xffu);
+    return max(max(n0, n1), max(n2, n3));
+}
+
+// Which of the wave's four 4x4 blocks the entry's 1/255-alpha box reaches; (bx, by) is the quadrant's origin.
+__device__ __forceinline__ void reach4(float gx, float gy, uint32_t reach, float bx, float by, bool valid,
+                                       unsigned long long& m0, unsigned long long& m1, unsigned long long& m2,
+                                       unsigned long long& m3) {
+    const float hx = __half2float(__ushort_as_half((unsigned short)(reach & 0xffffu)));
+    const float hy = __half2float(__ushort_as_half((unsigned short)(reach >> 16)));
+    const float x_hi = gx + hx, x_lo = gx - hx, y_hi = gy + hy, y_lo = gy - hy;
+    const bool inx0 = x_hi >= bx && x_lo <= bx + 3.0f, inx1 = x_hi >= bx + 4.0f && x_lo <= bx + 7.0f;
+    const bool iny0 = valid && y_hi >= by && y_lo <= by + 3.0f, iny1 = valid && y_hi >= by + 4.0f && y_lo <= by + 7.0f;
+    m0 = __ballot(inx0 && iny0); m1 = __ballot(inx1 && iny0);
+    m2 = __ballot(inx0 && iny1); m3 = __ballot(inx1 && iny1);
+}
+
+#define BL_LOG2E 1.4426950408889634f
 
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
     const int tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane >> 4, li = lane & 15;
     const int qx0 = tx * FDGS_TILE + (wave & 1) * 8, qy0 = ty * FDGS_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const int pxi = qx0 + 4 * (row & 1) + (li & 3), pyi = qy0 + 4 * (row >> 1) + (li >> 2);
     const int W = a.image_width, H = a.image_height;
     const bool inside = pxi < W && pyi < H;
     const float pxf = (float)pxi, pyf = (float)pyi;
-    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+    const float bx = (float)qx0, by = (float)qy0;
 
     const uint32_t r_begin = a.ranges[2 * tile], r_end = a.ranges[2 * tile + 1];
     const float4* __restrict__ geom4 = reinterpret_cast<const float4*>(a.geom);
 
-    __shared__ float4 staged[4][64 * BL_REC];
-    __shared__ float2 staged2[4][64];                       // forward: (b, depth)
+    __shared__ float4 staged[4][BL_SLOTS * 2];
+    __shared__ float2 staged2[4][BL_SLOTS];                 // forward: (b, depth)
     float4* __restrict__ my = staged[wave];
     float2* __restrict__ my2 = staged2[wave];
+    __shared__ unsigned char lists[4][4 * 64];              // per wave: the four rows' survivor lists of a batch
+    unsigned char* __restrict__ mylist = lists[wave];
+    if (lane == 0) {
+        my[BL_NULL * 2 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        my[BL_NULL * 2 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);      // opacity 0
+        my2[BL_NULL] = make_float2(0.f, 0.f);
+    }
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
     uint32_t last = 0;
     bool done = !inside;
 
     for (uint32_t base = r_begin; base < r_end; base += 64) {
-        if (__ballot(!done) == 0ull) break;
+        const unsigned long long live = __ballot(!done);
+        if (live == 0ull) break;
         const uint32_t e = base + lane;
         const bool valid = e < r_end;
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
@@ -55,37 +105,41 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
             g1 = geom4[3 * (size_t)id + 1];
             g2 = geom4[3 * (size_t)id + 2];
         }
-        my[lane * BL_REC + 0] = g0;
-        my[lane * BL_REC + 1] = g1;
+        my[lane * 2 + 0] = make_float4(g0.x, g0.y, -BL_LOG2E * g0.z, -BL_LOG2E * g0.w);
+        my[lane * 2 + 1] = make_float4(-BL_LOG2E * g1.x, g1.y, g1.z, g1.w);
         my2[lane] = make_float2(g2.x, g2.y);
-        const bool hit = valid && fdgs_reaches(g0.x, g0.y, __float_as_uint(g2.w), rx0, ry0, rx1, ry1);
-        unsigned long long mask = __ballot(hit);
-        if (mask == 0ull) continue;
-        while (true) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const bool more = mask != 0ull;
-            const float4 c0 = my[j * BL_REC + 0], c1 = my[j * BL_REC + 1];
+        unsigned long long m0, m1, m2, m3;
+        reach4(g0.x, g0.y, __float_as_uint(g2.w), bx, by, valid, m0, m1, m2, m3);
+        // a row whose sixteen pixels are all saturated takes no more entries
+        if ((live & 0xffffull) == 0ull) m0 = 0ull;
+        if ((live & 0xffff0000ull) == 0ull) m1 = 0ull;
+        if ((live & 0xffff00000000ull) == 0ull) m2 = 0ull;
+        if ((live & 0xffff000000000000ull) == 0ull) m3 = 0ull;
+        int mine;
+        const int steps = build_lists(mylist, m0, m1, m2, m3, lane, row, mine);
+        for (int t = 0; t < steps; ++t) {
+            const int j = t < mine ? (int)mylist[64 * row + t] : BL_NULL;
+            const float4 c0 = my[j * 2 + 0], c1 = my[j * 2 + 1];
             const float2 c2 = my2[j];
-            const float ex = c0.x, ey = c0.y, A = c0.z, B = c0.w, C = c1.x, o = c1.y;
-            const float dx = ex - pxf, dy = ey - pyf;
-            const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
-            const float alpha = fminf(FDGS_ALPHA_MAX, o * __expf(power));
+            const float dx = c0.x - pxf, dy = c0.y - pyf;
+            const float u = c0.z * dx, w = c1.x * dy, bdx = c0.w * dx;
+            const float power = 0.5f * (u * dx + w * dy) + bdx * dy;      // log2(e) x the exponent
+            const float alpha = fminf(FDGS_ALPHA_MAX, c1.y * __builtin_amdgcn_exp2f(power));
             if (!done && power <= 0.0f && alpha >= FDGS_ALPHA_MIN) {
                 const float test_T = T * (1.0f - alpha);
                 if (test_T < FDGS_T_STOP) {
                     done = true;
                 } else {
-                    const float w = alpha * T;
-                    Cr += c1.z * w;
-                    Cg += c1.w * w;
-                    Cb += c2.x * w;
-                    D += c2.y * w;
+                    const float wgt = alpha * T;
+                    Cr += c1.z * wgt;
+                    Cg += c1.w * wgt;
+                    Cb += c2.x * wgt;
+                    D += c2.y * wgt;
                     T = test_T;
                     last = (base - r_begin) + (uint32_t)j + 1u;
                 }
             }
-            if (!more || __ballot(!done) == 0ull) break;
+            if (__ballot(!done) == 0ull) break;
         }
     }
     if (inside) {
@@ -102,36 +156,23 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
 // ---------------------------------------------------------------------------
 // Backward
 // ---------------------------------------------------------------------------
-// Wave-wide sum; the total is returned from lane 63 (as a wave-uniform value).
-// Row-level Hillis-Steele steps with row_shr DPP, then the two cross-row
-// broadcasts (row_bcast:15, row_bcast:31) of the GCN/CDNA DPP set.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-    return v + __int_as_float(t);
+// DPP exchanges inside a 16-lane row: lane ^ 8 (row_ror:8), lane -> 7 - lane inside each 8-lane half
+// (row_half_mirror), lane ^ 2 and lane ^ 1 (quad_perm).
+template <int CTRL>
+__device__ __forceinline__ float dpp_from(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);   // row_shr:8
-    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    return bcast(v, 63);
-}
+#define DPP_ROR8 0x128
+#define DPP_HALF_MIRROR 0x141
+#define DPP_XOR2 0x4e
+#define DPP_XOR1 0xb1
 
-// x + (the other half-wave's y) arranged so that lanes 0-31 return sum-pairs of a, lanes 32-63 of b
-__device__ __forceinline__ float xswap32_add(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// same between the 16-lane rows of each half: even rows return pairs of a, odd rows pairs of b
-__device__ __forceinline__ float xswap16_add(float a, float b) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float ror8(float v) {   // lane i reads lane i^8 of its row
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+// One step of the transposing butterfly: two values in, one out; lanes where `upper` is false end up with the
+// pair sum of x, the others with the pair sum of y (the pair is the lane and its exchange partner).
+template <int CTRL>
+__device__ __forceinline__ float fold2(float x, float y, bool upper) {
+    const float keep = upper ? y : x, give = upper ? x : y;
+    return keep + dpp_from<CTRL>(give);
 }
 
 __global__ void __launch_bounds__(256)
@@ -139,12 +180,13 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     const int tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane >> 4, li = lane & 15;
     const int qx0 = tx * FDGS_TILE + (wave & 1) * 8, qy0 = ty * FDGS_TILE + (wave >> 1) * 8;
-    const int pxi = qx0 + (lane & 7), pyi = qy0 + (lane >> 3);
+    const int pxi = qx0 + 4 * (row & 1) + (li & 3), pyi = qy0 + 4 * (row >> 1) + (li >> 2);
     const int W = a.image_width, H = a.image_height;
     const bool inside = pxi < W && pyi < H;
     const float pxf = (float)pxi, pyf = (float)pyi;
-    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+    const float bx = (float)qx0, by = (float)qy0;
 
     const uint32_t r_begin = a.ranges[2 * tile], r_end = a.ranges[2 * tile + 1];
     if (r_begin >= r_end) return;
@@ -160,102 +202,139 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
         dLg = a.dL_dcolor[plane + pix];
         dLb = a.dL_dcolor[2 * plane + pix];
     }
-    const float bg_dot = a.bg[0] * dLr + a.bg[1] * dLg + a.bg[2] * dLb;
+    const float tb = -T_final * (a.bg[0] * dLr + a.bg[1] * dLg + a.bg[2] * dLb);
     float T = T_final;
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
 
-    int wave_last = ncon;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wave_last = max(wave_last, __shfl_xor(wave_last, d));
-    wave_last = __builtin_amdgcn_readfirstlane(wave_last);
+    // last contributor of each row's sixteen pixels, and of the wave
+    int row_last = ncon;
+    row_last = max(row_last, __builtin_amdgcn_update_dpp(0, row_last, DPP_XOR1, 0xf, 0xf, false));
+    row_last = max(row_last, __builtin_amdgcn_update_dpp(0, row_last, DPP_XOR2, 0xf, 0xf, false));
+    row_last = max(row_last, __builtin_amdgcn_update_dpp(0, row_last, DPP_HALF_MIRROR, 0xf, 0xf, false));
+    row_last = max(row_last, __builtin_amdgcn_update_dpp(0, row_last, DPP_ROR8, 0xf, 0xf, false));
+    const int last0 = __builtin_amdgcn_readlane(row_last, 0), last1 = __builtin_amdgcn_readlane(row_last, 16);
+    const int last2 = __builtin_amdgcn_readlane(row_last, 32), last3 = __builtin_amdgcn_readlane(row_last, 48);
+    const int wave_last = max(max(last0, last1), max(last2, last3));
 
-    __shared__ float4 staged[4][64 * BL_REC];
-    __shared__ float2 staged2[4][64];                       // backward: (b, Gaussian index)
+    __shared__ float4 staged[4][BL_SLOTS * 3];          // (x y a2 b1) (c2 o r g) (b, gradient-record byte offset lo, hi, -)
     float4* __restrict__ my = staged[wave];
-    float2* __restrict__ my2 = staged2[wave];
+    __shared__ unsigned char lists[4][4 * 64];          // per wave: the four rows' survivor lists of a batch
+    unsigned char* __restrict__ mylist = lists[wave];
+    if (lane == 0) {
+        my[BL_NULL * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        my[BL_NULL * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);      // opacity 0
+        my[BL_NULL * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // which of the nine sums this lane hands to memory: the butterfly leaves sum 4 b1 + 2 b2 + b3 (bits of the lane's
+    // position in its row) in every lane; even lanes store those eight, lane 1 of the row stores the ninth
+    const int comp = (li == 1) ? 8 : (((li >> 1) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 3) & 1));
+    const bool stores = (li & 1) == 0 || li == 1;
+    const bool up8 = (li & 8) != 0, up4 = (li & 4) != 0, up2 = (li & 2) != 0;
+    // The rows' sums are collected per batch entry in LDS (float64: LDS float32 atomics are an order of magnitude
+    // slower on this part) and handed to memory once per batch, nine consecutive floats per entry: the memory-side
+    // atomic units are paced by requests, not bytes, and one request per row and step - four records per
+    // instruction - made them the bottleneck.
+    __shared__ double sums[4][64 * 9];
+    double* __restrict__ mysum = sums[wave];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) mysum[64 * k + lane] = 0.0;
+    char* __restrict__ dbase = reinterpret_cast<char*>(a.dL_dgeom);
 
     for (int hi = wave_last; hi > 0; hi -= 64) {
         const int pos = hi - 1 - lane;        // 0-based position in the tile list, back to front
         const bool valid = pos >= 0;
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-        float2 g2 = make_float2(0.f, 0.f);
+        float gb = 0.f;
         uint32_t reach = 0xfc00fc00u;         // (-inf, -inf): reaches nothing
+        unsigned long long off = 0ull;
         if (valid) {
             const uint32_t id = a.point_list[r_begin + (uint32_t)pos];
             g0 = geom4[3 * (size_t)id + 0];
             g1 = geom4[3 * (size_t)id + 1];
-            g2.x = a.geom[FDGS_GEOM_FLOATS * (size_t)id + 8];
+            gb = a.geom[FDGS_GEOM_FLOATS * (size_t)id + 8];
             reach = __float_as_uint(a.geom[FDGS_GEOM_FLOATS * (size_t)id + 11]);
-            g2.y = __uint_as_float(id);       // the Gaussian's index travels with the record
+            off = (unsigned long long)id * (FDGS_GEOM_FLOATS * sizeof(float));
         }
-        my[lane * BL_REC + 0] = g0;
-        my[lane * BL_REC + 1] = g1;
-        my2[lane] = g2;
-        const bool hit = valid && fdgs_reaches(g0.x, g0.y, reach, rx0, ry0, rx1, ry1);
-        unsigned long long mask = __ballot(hit);
-        if (mask == 0ull) continue;
-        while (true) {
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1;
-            const bool more = mask != 0ull;
-            const float4 c0 = my[j * BL_REC + 0], c1 = my[j * BL_REC + 1];
-            const float2 c2 = my2[j];
+        my[lane * 3 + 0] = make_float4(g0.x, g0.y, -BL_LOG2E * g0.z, -BL_LOG2E * g0.w);
+        my[lane * 3 + 1] = make_float4(-BL_LOG2E * g1.x, g1.y, g1.z, g1.w);
+        my[lane * 3 + 2] = make_float4(gb, __uint_as_float((uint32_t)off), __uint_as_float((uint32_t)(off >> 32)), 0.f);
+        unsigned long long m0, m1, m2, m3;
+        reach4(g0.x, g0.y, reach, bx, by, valid, m0, m1, m2, m3);
+        // entries behind a row's last contributor cannot contribute to it
+        m0 &= __ballot(pos < last0); m1 &= __ballot(pos < last1);
+        m2 &= __ballot(pos < last2); m3 &= __ballot(pos < last3);
+        int mine;
+        const int steps = build_lists(mylist, m0, m1, m2, m3, lane, row, mine);
+        for (int t = 0; t < steps; ++t) {
+            const int j = t < mine ? (int)mylist[64 * row + t] : BL_NULL;
+            const float4 c0 = my[j * 3 + 0], c1 = my[j * 3 + 1];
             const int p = hi - 1 - j;
-            const float ex = c0.x, ey = c0.y, A = c0.z, B = c0.w, C = c1.x, o = c1.y;
-            const float dx = ex - pxf, dy = ey - pyf;
-            const float power = -0.5f * (A * dx * dx + C * dy * dy) - B * dx * dy;
-            const float G = __expf(power);
+            const float o = c1.y;
+            const float dx = c0.x - pxf, dy = c0.y - pyf;
+            const float u = c0.z * dx, w = c1.x * dy, bdx = c0.w * dx;
+            const float power = 0.5f * (u * dx + w * dy) + bdx * dy;      // log2(e) x the exponent
+            const float G = __builtin_amdgcn_exp2f(power);
             const float alpha = fminf(FDGS_ALPHA_MAX, o * G);
             const bool contrib = (p < ncon) && power <= 0.0f && alpha >= FDGS_ALPHA_MIN;
-            if (__ballot(contrib) != 0ull) {
-                // No divergent branch: a lane that does not contribute runs the same arithmetic with alpha = 0 and
-                // G = 0, which leaves its state unchanged bit for bit (T * rcp(1) = T; the pending (last_alpha,
-                // last colour) pair is folded into acc now instead of at the next contributor - the same single
-                // expression on the same operands - and the pair it leaves, alpha 0, folds as 0 * c + 1 * acc = acc)
-                // and makes all nine of its partial sums exact zeros.
-                const float al = contrib ? alpha : 0.0f;
-                const float Ge = contrib ? G : 0.0f;
-                const float cr = c1.z, cg = c1.w, cb = c2.x;
-                const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - al);   // 1 ulp; alpha <= 0.99
-                T = T * inv_one_m;
-                const float w = al * T;
-                acc_r = last_alpha * last_r + (1.0f - last_alpha) * acc_r;
-                acc_g = last_alpha * last_g + (1.0f - last_alpha) * acc_g;
-                acc_b = last_alpha * last_b + (1.0f - last_alpha) * acc_b;
-                last_r = cr; last_g = cg; last_b = cb;
-                float dL_dalpha = (cr - acc_r) * dLr + (cg - acc_g) * dLg + (cb - acc_b) * dLb;
-                const float v_r = w * dLr, v_g = w * dLg, v_b = w * dLb;
-                dL_dalpha *= T;
-                last_alpha = al;
-                dL_dalpha += (-T_final * inv_one_m) * bg_dot;
-                const float dL_dG = o * dL_dalpha;
-                const float gdx = Ge * dx, gdy = Ge * dy;
-                const float v_mx = dL_dG * (-gdx * A - gdy * B);
-                const float v_my = dL_dG * (-gdy * C - gdx * B);
-                const float v_A = -0.5f * gdx * dx * dL_dG;
-                const float v_B = -gdx * dy * dL_dG;
-                const float v_C = -0.5f * gdy * dy * dL_dG;
-                const float v_o = Ge * dL_dalpha;
-                // Eight of the nine partial sums go through a transposing butterfly: each exchange step halves
-                // the number of live registers (v_permlane32_swap / v_permlane16_swap trade one register's upper
-                // half for another's lower half; row_ror:8 does the same inside a 16-lane row), so that the 8-lane
-                // group g = lane>>3 ends up owning the total of value g.  The ninth takes the plain DPP reduction.
-                float t0 = xswap32_add(v_mx, v_C), t1 = xswap32_add(v_my, v_o);   // lanes <32: v[i], >=32: v[i+4]
-                float t2 = xswap32_add(v_A, v_r), t3 = xswap32_add(v_B, v_g);
-                const float u0 = xswap16_add(t0, t2), u1 = xswap16_add(t1, t3);  // rows with bit4: v[i+2]
-                const float a8 = u0 + ror8(u0), b8 = u1 + ror8(u1);
-                float r = (lane & 8) ? b8 : a8;                                   // bit3: v[i+1]
-                r = dpp_add<0x111, 0xf>(r);                                       // sum of each 8-lane group ...
-                r = dpp_add<0x112, 0xf>(r);
-                r = dpp_add<0x114, 0xf>(r);                                       // ... lands in lanes 8g+7
-                const float s8 = wave_sum(v_b);
-                const uint32_t gid = __float_as_uint(c2.y);
-                if ((lane & 7) == 7 || lane == 0) {
-                    const int comp = lane == 0 ? 8 : (lane >> 3);
-                    atomicAdd(a.dL_dgeom + (size_t)gid * FDGS_GEOM_FLOATS + comp, lane == 0 ? s8 : r);
-                }
+            if (__ballot(contrib) == 0ull) continue;
+            // No divergent branch: a lane that does not contribute runs the same arithmetic with alpha = 0 and
+            // G = 0, which leaves its state unchanged bit for bit (T * rcp(1) = T; the pending (last_alpha,
+            // last colour) pair is folded into acc now instead of at the next contributor - the same single
+            // expression on the same operands - and the pair it leaves, alpha 0, folds as 0 * c + 1 * acc = acc)
+            // and makes all nine of its partial sums exact zeros.
+            const float4 c2 = my[j * 3 + 2];
+            const float al = contrib ? alpha : 0.0f;
+            const float Ge = contrib ? G : 0.0f;
+            const float cr = c1.z, cg = c1.w, cb = c2.x;
+            const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - al);   // 1 ulp; alpha <= 0.99
+            T = T * inv_one_m;
+            const float wgt = al * T;
+            const float keep = 1.0f - last_alpha;
+            acc_r = last_alpha * last_r + keep * acc_r;
+            acc_g = last_alpha * last_g + keep * acc_g;
+            acc_b = last_alpha * last_b + keep * acc_b;
+            last_r = cr; last_g = cg; last_b = cb;
+            float dL_dalpha = (cr - acc_r) * dLr + (cg - acc_g) * dLg + (cb - acc_b) * dLb;
+            const float v_r = wgt * dLr, v_g = wgt * dLg, v_b = wgt * dLb;
+            last_alpha = al;
+            dL_dalpha = dL_dalpha * T + tb * inv_one_m;
+            const float v_o = Ge * dL_dalpha;
+            const float g = o * v_o;                                    // dL/d(exponent), in the exponent's own scale
+            const float gdx = g * dx, gdy = g * dy;
+            const float v_mx = g * (u + c0.w * dy);                     // FDGS_DGEOM_* scaling, see fdgs_common.h
+            const float v_my = g * (w + bdx);
+            const float v_A = gdx * dx, v_B = gdx * dy, v_C = gdy * dy;
+            // Eight of the nine partial sums go through a transposing butterfly inside the 16-lane row: each exchange
+            // step halves the number of live registers, and after the fourth every lane of the row holds the row's
+            // total of one sum (which one: `comp`).  The ninth takes four plain exchange-and-add steps.
+            const float a0 = fold2<DPP_ROR8>(v_mx, v_my, up8), a1 = fold2<DPP_ROR8>(v_A, v_B, up8);
+            const float a2 = fold2<DPP_ROR8>(v_C, v_o, up8), a3 = fold2<DPP_ROR8>(v_r, v_g, up8);
+            const float b0 = fold2<DPP_HALF_MIRROR>(a0, a1, up4), b1 = fold2<DPP_HALF_MIRROR>(a2, a3, up4);
+            float r = fold2<DPP_XOR2>(b0, b1, up2);
+            r += dpp_from<DPP_XOR1>(r);
+            float s = v_b + dpp_from<DPP_XOR1>(v_b);
+            s += dpp_from<DPP_XOR2>(s);
+            s += dpp_from<DPP_HALF_MIRROR>(s);
+            s += dpp_from<DPP_ROR8>(s);
+            const float out = (li == 1) ? s : r;
+            if (stores && out != 0.0f)          // an exhausted or untouched row has nothing to add
+                atomicAdd(&mysum[j * 9 + comp], (double)out);
+        }
+        if (steps == 0) continue;
+        // hand the batch's sums to memory and leave the LDS slots zero: slot q = 9 entry + component
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int q = 64 * k + lane;
+            const int e = (q * 7282) >> 16;                          // q / 9 for q < 576
+            const unsigned long long bits =
+                atomicExch(reinterpret_cast<unsigned long long*>(&mysum[q]), 0ull);
+            const float f = (float)__longlong_as_double((long long)bits);
+            if (f != 0.0f) {
+                const float4 rec = my[e * 3 + 2];
+                const unsigned long long goff = (unsigned long long)__float_as_uint(rec.y) |
+                                                ((unsigned long long)__float_as_uint(rec.z) << 32);
+                atomicAdd(reinterpret_cast<float*>(dbase + goff + 4 * (q - 9 * e)), f);
             }
-            if (!more) break;
         }
     }
 }

@@ -148,8 +148,10 @@ typedef struct {
     const float* final_T;
     const uint32_t* n_contrib;
     const float* dL_dcolor;          /* [3,H,W]                                     */
-    /* output: per-Gaussian accumulators, MUST be zero on entry.  [N,12]:
-     *   [0] dL/dx_pix [1] dL/dy_pix [2] dL/dA [3] dL/dB [4] dL/dC [5] dL/dopacity
+    /* output: per-Gaussian accumulators, MUST be zero on entry.  [N,12], to be handed to
+     * fdgs_raster_preprocess_bwd as they are (slots 0-4 are in the scaling of the blending loop, which stages the
+     * conic multiplied by -log2(e); preprocess_bwd applies the constants):
+     *   [0] log2(e) dL/dx_pix [1] log2(e) dL/dy_pix [2] -2 dL/dA [3] -dL/dB [4] -2 dL/dC [5] dL/dopacity
      *   [6..8] dL/drgb  [9..11] unused                                            */
     float* dL_dgeom;
 } fdgs_blend_bwd_args;
