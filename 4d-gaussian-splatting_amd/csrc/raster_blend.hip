@@ -46,8 +46,28 @@ __device__ __forceinline__ int build_lists(unsigned char* __restrict__ lists, un
     return max(max(n0, n1), max(n2, n3));
 }
 
-// Which of the wave's four 4x4 blocks the entry's 1/255-alpha box reaches; (bx, by) is the quadrant's origin.
-__device__ __forceinline__ void reach4(float gx, float gy, uint32_t reach, float bx, float by, bool valid,
+// Can the splat's alpha reach 1/255 at some pixel centre of the rectangle [ex0, ex1] x [ey0, ey1] (coordinates
+// relative to the splat's centre)?  The exponent E(dx, dy) = (a2 dx^2 + c2 dy^2) / 2 + b1 dx dy (in log2 units,
+// a2, c2 < 0) is concave with its maximum 0 at the centre, so over a rectangle that does not contain the centre it
+// peaks on an edge facing the centre; on the edge dx = e the best dy is -b1 e / c2 clipped to the edge.
+// tau = the exponent at which alpha = 1/255, lowered by a margin that covers the rounding of this test and of
+// the per-pixel evaluation.  Anything undecidable (degenerate conic, NaN) counts as reachable.
+__device__ __forceinline__ bool exponent_reaches(float ex0, float ex1, float ey0, float ey1, float a2, float b1,
+                                                 float c2, float inv_a2, float inv_c2, float tau) {
+    const bool in_x = ex0 <= 0.0f && ex1 >= 0.0f, in_y = ey0 <= 0.0f && ey1 >= 0.0f;
+    const float e_x = ex0 > 0.0f ? ex0 : ex1, e_y = ey0 > 0.0f ? ey0 : ey1;
+    const float ty = fminf(fmaxf(-b1 * e_x * inv_c2, ey0), ey1);
+    const float tx = fminf(fmaxf(-b1 * e_y * inv_a2, ex0), ex1);
+    const float on_v = 0.5f * a2 * e_x * e_x + ty * (b1 * e_x + 0.5f * c2 * ty);     // best on the edge dx = e_x
+    const float on_h = 0.5f * c2 * e_y * e_y + tx * (b1 * e_y + 0.5f * a2 * tx);     // best on the edge dy = e_y
+    const float best = in_x ? on_h : (in_y ? on_v : fmaxf(on_v, on_h));
+    return (in_x && in_y) || !(best < tau);
+}
+
+// Which of the wave's four 4x4 blocks the entry can contribute to; (bx, by) is the quadrant's origin.  First the
+// precomputed box of the 1/255-alpha ellipse (fdgs_pack_reach), then the ellipse itself against each block.
+__device__ __forceinline__ void reach4(float gx, float gy, uint32_t reach, float a2, float b1, float c2, float o,
+                                       float bx, float by, bool valid,
                                        unsigned long long& m0, unsigned long long& m1, unsigned long long& m2,
                                        unsigned long long& m3) {
     const float hx = __half2float(__ushort_as_half((unsigned short)(reach & 0xffffu)));
@@ -55,8 +75,17 @@ __device__ __forceinline__ void reach4(float gx, float gy, uint32_t reach, float
     const float x_hi = gx + hx, x_lo = gx - hx, y_hi = gy + hy, y_lo = gy - hy;
     const bool inx0 = x_hi >= bx && x_lo <= bx + 3.0f, inx1 = x_hi >= bx + 4.0f && x_lo <= bx + 7.0f;
     const bool iny0 = valid && y_hi >= by && y_lo <= by + 3.0f, iny1 = valid && y_hi >= by + 4.0f && y_lo <= by + 7.0f;
-    m0 = __ballot(inx0 && iny0); m1 = __ballot(inx1 && iny0);
-    m2 = __ballot(inx0 && iny1); m3 = __ballot(inx1 && iny1);
+    const bool conic_ok = a2 < 0.0f && c2 < 0.0f;
+    const float inv_a2 = conic_ok ? __builtin_amdgcn_rcpf(a2) : 0.0f, inv_c2 = conic_ok ? __builtin_amdgcn_rcpf(c2) : 0.0f;
+    const float t0 = -__builtin_amdgcn_logf(255.0f * o);            // v_log_f32 is log2
+    const float tau = conic_ok ? t0 - (0.001f * fabsf(t0) + 0.001f) : -__builtin_inff();
+    const float ex = bx - gx, ey = by - gy;
+    const bool r0 = exponent_reaches(ex, ex + 3.0f, ey, ey + 3.0f, a2, b1, c2, inv_a2, inv_c2, tau);
+    const bool r1 = exponent_reaches(ex + 4.0f, ex + 7.0f, ey, ey + 3.0f, a2, b1, c2, inv_a2, inv_c2, tau);
+    const bool r2 = exponent_reaches(ex, ex + 3.0f, ey + 4.0f, ey + 7.0f, a2, b1, c2, inv_a2, inv_c2, tau);
+    const bool r3 = exponent_reaches(ex + 4.0f, ex + 7.0f, ey + 4.0f, ey + 7.0f, a2, b1, c2, inv_a2, inv_c2, tau);
+    m0 = __ballot(inx0 && iny0 && r0); m1 = __ballot(inx1 && iny0 && r1);
+    m2 = __ballot(inx0 && iny1 && r2); m3 = __ballot(inx1 && iny1 && r3);
 }
 
 #define BL_LOG2E 1.4426950408889634f
@@ -105,11 +134,12 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
             g1 = geom4[3 * (size_t)id + 1];
             g2 = geom4[3 * (size_t)id + 2];
         }
-        my[lane * 2 + 0] = make_float4(g0.x, g0.y, -BL_LOG2E * g0.z, -BL_LOG2E * g0.w);
-        my[lane * 2 + 1] = make_float4(-BL_LOG2E * g1.x, g1.y, g1.z, g1.w);
+        const float sa2 = -BL_LOG2E * g0.z, sb1 = -BL_LOG2E * g0.w, sc2 = -BL_LOG2E * g1.x;
+        my[lane * 2 + 0] = make_float4(g0.x, g0.y, sa2, sb1);
+        my[lane * 2 + 1] = make_float4(sc2, g1.y, g1.z, g1.w);
         my2[lane] = make_float2(g2.x, g2.y);
         unsigned long long m0, m1, m2, m3;
-        reach4(g0.x, g0.y, __float_as_uint(g2.w), bx, by, valid, m0, m1, m2, m3);
+        reach4(g0.x, g0.y, __float_as_uint(g2.w), sa2, sb1, sc2, g1.y, bx, by, valid, m0, m1, m2, m3);
         // a row whose sixteen pixels are all saturated takes no more entries
         if ((live & 0xffffull) == 0ull) m0 = 0ull;
         if ((live & 0xffff0000ull) == 0ull) m1 = 0ull;
@@ -255,11 +285,12 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
             reach = __float_as_uint(a.geom[FDGS_GEOM_FLOATS * (size_t)id + 11]);
             off = (unsigned long long)id * (FDGS_GEOM_FLOATS * sizeof(float));
         }
-        my[lane * 3 + 0] = make_float4(g0.x, g0.y, -BL_LOG2E * g0.z, -BL_LOG2E * g0.w);
-        my[lane * 3 + 1] = make_float4(-BL_LOG2E * g1.x, g1.y, g1.z, g1.w);
+        const float sa2 = -BL_LOG2E * g0.z, sb1 = -BL_LOG2E * g0.w, sc2 = -BL_LOG2E * g1.x;
+        my[lane * 3 + 0] = make_float4(g0.x, g0.y, sa2, sb1);
+        my[lane * 3 + 1] = make_float4(sc2, g1.y, g1.z, g1.w);
         my[lane * 3 + 2] = make_float4(gb, __uint_as_float((uint32_t)off), __uint_as_float((uint32_t)(off >> 32)), 0.f);
         unsigned long long m0, m1, m2, m3;
-        reach4(g0.x, g0.y, reach, bx, by, valid, m0, m1, m2, m3);
+        reach4(g0.x, g0.y, reach, sa2, sb1, sc2, g1.y, bx, by, valid, m0, m1, m2, m3);
         // entries behind a row's last contributor cannot contribute to it
         m0 &= __ballot(pos < last0); m1 &= __ballot(pos < last1);
         m2 &= __ballot(pos < last2); m3 &= __ballot(pos < last3);
