@@ -1230,7 +1230,12 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f], db0 = column sums of dhid (split mode): the same split product as
     // the dW1 kernels with one 32-column block.  yfeat: the features as points-as-K pieces from the forward, or
     // NULL to build them from ws_feat (written by the HexPlane backward, so only after it).
-    auto launch_dw0_split = [&](hipStream_t hs, const u32x4* yfeat) -> int {
+    // fold_later: leave the fold of the private copies to the launch that folds the dW2 / db2 copies at the end of
+    // the call (a launch of its own in the middle of the weight-gradient chain waited 45 us for a free slot on
+    // the busy chip)
+    float* dw0_slab_w = nullptr;
+    float* dw0_slab_b = nullptr;
+    auto launch_dw0_split = [&](hipStream_t hs, const u32x4* yfeat, bool fold_later) -> int {
         const int chunks = (n + 15) / 16;
         if (!yfeat) {
             WGradPrepK pk;
@@ -1259,6 +1264,11 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         if (!a->dp.w0) w1.d[0].C = nullptr;
         hipLaunchKernelGGL(deform_wgrad_split_kernel<1>, dim3((chunks + per - 1) / per, 1), dim3(256), 0, hs, w1);
         FDGS_CHECK_LAUNCH();
+        if (fold_later) {
+            dw0_slab_w = a->dp.w0 ? slab_w : nullptr;
+            dw0_slab_b = (a->dp.w0 && a->dp.b0) ? slab_b : nullptr;
+            return FDGS_OK;
+        }
         SlabReduceK sr;
         for (int e = 0; e < SLAB_ENTRIES; ++e) { sr.slab[e] = nullptr; sr.out[e] = nullptr; sr.count[e] = 0; sr.stride[e] = 0; }
         sr.slab[0] = slab_w; sr.out[0] = a->dp.w0; sr.count[0] = DW * 32; sr.stride[0] = DW * 32;
@@ -1347,7 +1357,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         }
         if (a->p.matmul == FDGS_MATMUL_SPLIT_BF16) {
             if (!a->yfeat) {                        // with the forward's pieces this product is already on its way
-                rc = launch_dw0_split(hs, nullptr);
+                rc = launch_dw0_split(hs, nullptr, false);
                 if (rc != FDGS_OK) return rc;
             }
         } else {                                    // dW0[nn][f] = sum_p dhid[p][nn] * feat[p][f]  (fp32 MFMA)
@@ -1427,7 +1437,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                 if (hipEventRecord(side->join, side->stream) != hipSuccess) return FDGS_ELAUNCH;
             }
             if (split && a->yfeat) {            // needs dhid only: runs beside the HexPlane backward, not after it
-                rc = launch_dw0_split(s, reinterpret_cast<const u32x4*>(a->yfeat));
+                rc = launch_dw0_split(s, reinterpret_cast<const u32x4*>(a->yfeat), true);
                 if (rc != FDGS_OK) return rc;
             }
         }
@@ -1532,8 +1542,11 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             sr.slab[5 + h] = w2_slabs + (size_t)W2_SLABS * 59 * DW + 64 * h; sr.out[5 + h] = a->dp.b2[h];
             sr.count[5 + h] = kdim[h]; sr.stride[5 + h] = 5 * 64;
         }
+        static_assert(DW0_SLABS == W2_SLABS && SLAB_ENTRIES >= 12, "one fold launch for both sets of copies");
+        if (dw0_slab_w) { sr.slab[10] = dw0_slab_w; sr.out[10] = a->dp.w0; sr.count[10] = DW * 32; sr.stride[10] = DW * 32; }
+        if (dw0_slab_b) { sr.slab[11] = dw0_slab_b; sr.out[11] = a->dp.b0; sr.count[11] = DW; sr.stride[11] = DW; }
         sr.slabs = W2_SLABS;
-        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(8, 10), dim3(256), 0, s, sr);
+        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(8, 12), dim3(256), 0, s, sr);
         FDGS_CHECK_LAUNCH();
     }
     if (side) {                                 // join

@@ -1,7 +1,10 @@
 // Stage 4: stable LSD radix sort of (uint64 key, uint32 value) pairs for gfx950.
 //
-// 9-bit digits (the 45 key bits of a 1352 x 1014 frame - 13 tile bits + 32 depth bits - take five passes instead
-// of the six that 8-bit digits need).  Per pass three launches:
+// Digits of up to RS_BITS bits, the key bits divided evenly over the passes: the keys of a 1352 x 1014 frame are 13
+// tile bits + the bits of the frame's depth range (26-27 for depths between 0.2 and a few hundred, when the caller
+// knows the range; 32 otherwise): five passes, six without the range.  (Ten-bit digits need one pass fewer, but the
+// 1024-entry tables per 2048-key sub-tile make each pass a third slower: measured 38 us against 29 us a pass.)
+// Per pass three launches:
 //   1. digit histogram per block (LDS atomics), stored digit-major  hist[d][block]
 //   2. one block per digit: exclusive scan of its row + the digit total
 //   3. scatter: each block walks its range in sub-tiles of 2048 keys; ranks are
@@ -17,8 +20,9 @@
 #define RS_IPL 8                                    // items per lane
 #define RS_SUBTILE (RS_THREADS * RS_IPL)            // 2048 keys
 #define RS_MAX_BLOCKS 1024
-#define RS_BITS 9
-#define RS_BINS (1 << RS_BITS)                       // 512: two digits per thread where a thread owns digits
+#define RS_BITS 8
+#define RS_BINS (1 << RS_BITS)
+#define RS_DPT ((RS_BINS + RS_THREADS - 1) / RS_THREADS)   // digits a thread owns where threads own digits
 
 struct rs_plan {
     int blocks;
@@ -99,17 +103,23 @@ __global__ void __launch_bounds__(RS_THREADS)
 rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                   uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int64_t per_block,
                   int shift, uint32_t mask, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
-                  int nblocks) {
+                  int nblocks, int digit_bits, int expand_bits, uint32_t expand_add) {
     __shared__ uint32_t running[RS_BINS];          // next global slot per digit for this block
     __shared__ uint32_t wave_cnt[4][RS_BINS];      // per-wave digit counts, then per-wave bases
     __shared__ uint32_t wsum[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-    // digit base = exclusive scan of the RS_BINS totals (thread t owns digits 2t and 2t+1), + this block's prefix
+    // digit base = exclusive scan of the RS_BINS totals (thread t owns digits RS_DPT*t ...), + this block's prefix
     // inside the digit row
     {
-        const uint32_t t0 = totals[2 * threadIdx.x], t1 = totals[2 * threadIdx.x + 1];
-        const uint32_t t = t0 + t1;
+        const int d0 = RS_DPT * threadIdx.x;
+        uint32_t tt[RS_DPT];
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < RS_DPT; ++k) {
+            tt[k] = d0 + k < RS_BINS ? totals[d0 + k] : 0u;
+            t += tt[k];
+        }
         uint32_t incl = t;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -122,9 +132,12 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
 #pragma unroll
         for (int w = 0; w < 4; ++w)
             if (w < wave) base += wsum[w];
-        const uint32_t excl = base + incl - t;
-        running[2 * threadIdx.x] = excl + hist[(size_t)(2 * threadIdx.x) * nblocks + blockIdx.x];
-        running[2 * threadIdx.x + 1] = excl + t0 + hist[(size_t)(2 * threadIdx.x + 1) * nblocks + blockIdx.x];
+        uint32_t excl = base + incl - t;
+#pragma unroll
+        for (int k = 0; k < RS_DPT; ++k) {
+            if (d0 + k < RS_BINS) running[d0 + k] = excl + hist[(size_t)(d0 + k) * nblocks + blockIdx.x];
+            excl += tt[k];
+        }
     }
 
     const int64_t begin = (int64_t)blockIdx.x * per_block;
@@ -158,8 +171,10 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
             unsigned long long peers = __ballot(ok);
 #pragma unroll
             for (int b = 0; b < RS_BITS; ++b) {
-                const unsigned long long bal = __ballot((d >> b) & 1u);
-                peers &= ((d >> b) & 1u) ? bal : ~bal;
+                if (b < digit_bits) {
+                    const unsigned long long bal = __ballot((d >> b) & 1u);
+                    peers &= ((d >> b) & 1u) ? bal : ~bal;
+                }
             }
             const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
             uint32_t prev = 0;
@@ -185,7 +200,11 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
             if (idx < end) {
                 const uint32_t d = (uint32_t)(key[k] >> shift) & mask;
                 const uint32_t dst = wave_cnt[wave][d] + rank[k];
-                keys_out[dst] = key[k];
+                // last pass of a compressed sort: back to (tile << 32) | depth bits
+                const uint64_t ko = expand_bits ? (((key[k] >> expand_bits) << 32) |
+                                                   (uint64_t)((uint32_t)(key[k] & ((1ull << expand_bits) - 1ull)) + expand_add))
+                                                : key[k];
+                keys_out[dst] = ko;
                 vals_out[dst] = val[k];
             }
         }
@@ -193,23 +212,26 @@ rs_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restri
     }
 }
 
-// Number of RS_BITS-bit passes needed for bits [0,end_bit).
-int fdgs_radix_sort_passes(int end_bit) { return (end_bit + RS_BITS - 1) / RS_BITS; }
+// Number of passes (digits of at most RS_BITS bits) needed for bits [0,end_bit).
+int fdgs_radix_sort_passes(int end_bit) { return end_bit <= 0 ? 1 : (end_bit + RS_BITS - 1) / RS_BITS; }
 
 // Sorts n pairs.  Pass p reads buffer (p even ? A : B) and writes the other one,
 // where A = (keys_a, vals_a).  The result is in B after an odd number of passes
 // and in A after an even number; the caller picks A/B accordingly.
+// expand_bits != 0: the keys are (tile << expand_bits) | low; the last pass writes (tile << 32) | (low + expand_add).
 int fdgs_radix_sort_pingpong(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int64_t n,
-                             int end_bit, void* workspace, size_t workspace_bytes, hipStream_t s) {
+                             int end_bit, void* workspace, size_t workspace_bytes, hipStream_t s, int expand_bits,
+                             uint32_t expand_add) {
     if (n <= 0) return FDGS_OK;
     if (workspace_bytes < fdgs_raster_sort_workspace_bytes(n)) return FDGS_EWORKSPACE;
     uint32_t* hist = (uint32_t*)workspace;
     uint32_t* totals = hist + (size_t)RS_BINS * RS_MAX_BLOCKS;
     const rs_plan plan = rs_make_plan(n);
     const int passes = fdgs_radix_sort_passes(end_bit);
-    for (int p = 0; p < passes; ++p) {
-        const int shift = RS_BITS * p;
-        const int bits = (end_bit - shift) < RS_BITS ? (end_bit - shift) : RS_BITS;
+    if (end_bit < 1) end_bit = 1;
+    int shift = 0;
+    for (int p = 0; p < passes; ++p, shift += 0) {
+        const int bits = (end_bit - shift + (passes - p) - 1) / (passes - p);      // the remaining bits, evenly
         const uint32_t mask = (1u << bits) - 1u;
         const uint64_t* kin = (p & 1) ? keys_b : keys_a;
         const uint32_t* vin = (p & 1) ? vals_b : vals_a;
@@ -220,9 +242,12 @@ int fdgs_radix_sort_pingpong(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_
         FDGS_CHECK_LAUNCH();
         hipLaunchKernelGGL(rs_rowscan_kernel, dim3(RS_BINS), dim3(RS_THREADS), 0, s, hist, totals, plan.blocks);
         FDGS_CHECK_LAUNCH();
+        const bool last = p == passes - 1;
         hipLaunchKernelGGL(rs_scatter_kernel, dim3(plan.blocks), dim3(RS_THREADS), 0, s, kin, vin, kout, vout, n,
-                           plan.per_block, shift, mask, hist, totals, plan.blocks);
+                           plan.per_block, shift, mask, hist, totals, plan.blocks, bits, last ? expand_bits : 0,
+                           expand_add);
         FDGS_CHECK_LAUNCH();
+        shift += bits;
     }
     return FDGS_OK;
 }

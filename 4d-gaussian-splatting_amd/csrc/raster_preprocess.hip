@@ -187,6 +187,9 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
                           __uint_as_float(visible ? fdgs_pack_reach(conA, conB, conC, op) : 0xfc00fc00u));
     a.radii[i] = radius;
     a.tiles_touched[i] = touched;
+    // until the scan writes it, point_offsets carries the depth bits of the Gaussians that enter the tile lists
+    // (0 otherwise: a listed depth is > 0.2): the scan kernels reduce them to the frame's depth range
+    a.point_offsets[i] = touched ? __float_as_uint(pvz) : 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -224,31 +227,68 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* to
     return base + incl - v;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS)
-scan_chunk_sums_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ chunk_sums, int n) {
-    __shared__ uint32_t lds4[4];
-    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
+// Scan workspace: [0] smallest and [1] largest depth bit pattern among the listed Gaussians (0xffffffff / 0 when
+// there are none), [2] R = the total, [3] unused, then per chunk: sum -> exclusive base, depth minimum, depth maximum.
+#define SCAN_HEADER 4
+
+__device__ __forceinline__ void block_minmax_256(uint32_t& lo, uint32_t& hi, uint32_t* lds8) {
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) s += in[base + k];
-    uint32_t total;
-    block_excl_scan_256(s, &total, lds4);
-    if (threadIdx.x == 0) chunk_sums[blockIdx.x] = total;
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { lds8[wave] = lo; lds8[4 + wave] = hi; }
+    __syncthreads();
+    lo = min(min(lds8[0], lds8[1]), min(lds8[2], lds8[3]));
+    hi = max(max(lds8[4], lds8[5]), max(lds8[6], lds8[7]));
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_chunk_bases_kernel(uint32_t* __restrict__ chunk_sums, int n_chunks) {
+scan_chunk_sums_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ depth_bits,
+                       uint32_t* __restrict__ ws, int n, int n_chunks) {
     __shared__ uint32_t lds4[4];
-    uint32_t carry = 0;
+    __shared__ uint32_t lds8[8];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0, lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) {
+            s += in[base + k];
+            const uint32_t d = depth_bits[base + k];
+            if (d != 0u) { lo = min(lo, d); hi = max(hi, d); }
+        }
+    uint32_t total;
+    block_excl_scan_256(s, &total, lds4);
+    block_minmax_256(lo, hi, lds8);
+    if (threadIdx.x == 0) {
+        ws[SCAN_HEADER + blockIdx.x] = total;
+        ws[SCAN_HEADER + n_chunks + blockIdx.x] = lo;
+        ws[SCAN_HEADER + 2 * n_chunks + blockIdx.x] = hi;
+    }
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_chunk_bases_kernel(uint32_t* __restrict__ ws, int n_chunks) {
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t lds8[8];
+    uint32_t* __restrict__ chunk_sums = ws + SCAN_HEADER;
+    uint32_t carry = 0, lo = 0xffffffffu, hi = 0u;
     for (int start = 0; start < n_chunks; start += SCAN_THREADS) {
         const int idx = start + threadIdx.x;
         uint32_t v = idx < n_chunks ? chunk_sums[idx] : 0u;
+        if (idx < n_chunks) {
+            lo = min(lo, chunk_sums[n_chunks + idx]);
+            hi = max(hi, chunk_sums[2 * n_chunks + idx]);
+        }
         uint32_t total;
         uint32_t excl = block_excl_scan_256(v, &total, lds4);
         if (idx < n_chunks) chunk_sums[idx] = carry + excl;   // exclusive base of the chunk
         carry += total;
     }
+    block_minmax_256(lo, hi, lds8);
+    if (threadIdx.x == 0) { ws[0] = lo; ws[1] = hi; ws[2] = carry; ws[3] = 0u; }
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
@@ -264,7 +304,7 @@ scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ 
         s += v[k];
     }
     uint32_t total;
-    uint32_t run = chunk_bases[blockIdx.x] + block_excl_scan_256(s, &total, lds4);
+    uint32_t run = chunk_bases[SCAN_HEADER + blockIdx.x] + block_excl_scan_256(s, &total, lds4);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         run += v[k];
@@ -274,11 +314,14 @@ scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ 
 
 // ---------------------------------------------------------------------------
 // Stage 3: duplicateWithKeys.  One thread per Gaussian writes one (key,value)
-// per touched tile, tiles row-major.  key = (tile_id << 32) | bits(depth).
+// per touched tile, tiles row-major.  key = (tile_id << 32) | bits(depth); when the
+// frame's depth range is known, in the order-preserving compressed form
+// (tile_id << depth_bits) | (bits(depth) - depth_min), which the sort's last pass expands again.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int n, const float* __restrict__ geom, const uint32_t* __restrict__ offsets,
-                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, int gy) {
+                           uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, int gy,
+                           int depth_bits, uint32_t depth_min) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 g2 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 2];
@@ -288,10 +331,10 @@ duplicate_with_keys_kernel(int n, const float* __restrict__ geom, const uint32_t
     uint32_t off = (i == 0) ? 0u : offsets[i - 1];
     int x0, y0, x1, y1;
     fdgs_tile_rect(g0.x, g0.y, (float)radius, gx, gy, x0, y0, x1, y1);
-    const uint64_t dbits = (uint64_t)__float_as_uint(g2.y);
+    const uint64_t dbits = (uint64_t)(__float_as_uint(g2.y) - depth_min);
     for (int ty = y0; ty < y1; ++ty)
         for (int tx = x0; tx < x1; ++tx) {
-            keys[off] = ((uint64_t)(uint32_t)(ty * gx + tx) << 32) | dbits;
+            keys[off] = ((uint64_t)(uint32_t)(ty * gx + tx) << depth_bits) | dbits;
             vals[off] = (uint32_t)i;
             ++off;
         }
@@ -322,7 +365,7 @@ identify_tile_ranges_kernel(int64_t R, const uint64_t* __restrict__ keys, uint32
 extern "C" size_t fdgs_raster_scan_workspace_bytes(int32_t num_points) {
     if (num_points < 0) return 0;
     size_t chunks = ((size_t)num_points + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    return (chunks + 1) * sizeof(uint32_t);
+    return (SCAN_HEADER + 3 * chunks + 1) * sizeof(uint32_t);
 }
 
 extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, void* stream) {
@@ -340,7 +383,7 @@ extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, voi
     FDGS_CHECK_LAUNCH();
     const int chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
     hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
-                       a->scan_workspace, n);
+                       a->point_offsets, a->scan_workspace, n, chunks);
     FDGS_CHECK_LAUNCH();
     hipLaunchKernelGGL(scan_chunk_bases_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, a->scan_workspace, chunks);
     FDGS_CHECK_LAUNCH();
@@ -353,7 +396,8 @@ extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, voi
 // sort lives in radix_sort.hip
 int fdgs_radix_sort_passes(int end_bit);
 int fdgs_radix_sort_pingpong(uint64_t* keys_a, uint32_t* vals_a, uint64_t* keys_b, uint32_t* vals_b, int64_t n,
-                             int end_bit, void* workspace, size_t workspace_bytes, hipStream_t s);
+                             int end_bit, void* workspace, size_t workspace_bytes, hipStream_t s, int expand_bits,
+                             uint32_t expand_add);
 
 extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
     if (!a || a->num_points < 0 || a->num_rendered < 0 || a->image_width <= 0 || a->image_height <= 0)
@@ -372,7 +416,18 @@ extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
     if (a->sort_workspace_bytes < fdgs_raster_sort_workspace_bytes(R)) return FDGS_EWORKSPACE;
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;   // keys are < tiles << 32
-    const int end_bit = 32 + tile_bits;
+    // With the frame's depth range (the first two words fdgs_raster_preprocess_fwd leaves in its scan workspace) the
+    // keys are sorted as (tile << k) | (depth bits - minimum), k = the bits of (maximum - minimum): the same order
+    // on fewer digits; the last pass writes the keys back in the (tile << 32) | depth bits form.
+    int depth_bits = 32;
+    uint32_t depth_min = 0;
+    if (a->depth_bits_max >= a->depth_bits_min && a->depth_bits_max != 0) {
+        depth_min = a->depth_bits_min;
+        const uint32_t span = a->depth_bits_max - a->depth_bits_min;
+        depth_bits = 1;
+        while (depth_bits < 32 && (span >> depth_bits) != 0) ++depth_bits;
+    }
+    const int end_bit = depth_bits + tile_bits;
     // The sort ping-pongs between the two buffer pairs; start in the pair that
     // makes the last pass land in keys_sorted / vals_sorted.
     const bool odd = fdgs_radix_sort_passes(end_bit) & 1;
@@ -381,9 +436,10 @@ extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
     uint64_t* kb = odd ? a->keys_sorted : a->keys_unsorted;
     uint32_t* vb = odd ? a->vals_sorted : a->vals_unsorted;
     hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((a->num_points + 255) / 256), dim3(256), 0, s, a->num_points,
-                       a->geom, a->point_offsets, ka, va, gx, gy);
+                       a->geom, a->point_offsets, ka, va, gx, gy, depth_bits, depth_min);
     FDGS_CHECK_LAUNCH();
-    int rc = fdgs_radix_sort_pingpong(ka, va, kb, vb, R, end_bit, a->sort_workspace, a->sort_workspace_bytes, s);
+    int rc = fdgs_radix_sort_pingpong(ka, va, kb, vb, R, end_bit, a->sort_workspace, a->sort_workspace_bytes, s,
+                                      depth_bits < 32 || depth_min != 0 ? depth_bits : 0, depth_min);
     if (rc != FDGS_OK) return rc;
     hipLaunchKernelGGL(identify_tile_ranges_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R,
                        a->keys_sorted, a->ranges);

@@ -37,7 +37,8 @@ class BinSortArgs(C.Structure):
     _fields_ = [("num_points", c_i32), ("image_width", c_i32), ("image_height", c_i32), ("num_rendered", c_i64),
                 ("geom", c_p), ("point_offsets", c_p),
                 ("keys_unsorted", c_p), ("vals_unsorted", c_p), ("keys_sorted", c_p), ("vals_sorted", c_p),
-                ("ranges", c_p), ("sort_workspace", c_p), ("sort_workspace_bytes", c_sz)]
+                ("ranges", c_p), ("sort_workspace", c_p), ("sort_workspace_bytes", c_sz),
+                ("depth_bits_min", C.c_uint32), ("depth_bits_max", C.c_uint32)]
 
 
 class BlendFwdArgs(C.Structure):
@@ -225,7 +226,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 def _load():

@@ -73,7 +73,7 @@ class ViewPipeline:
         self.sets = [dict(xyz=e(N, 3), means3D=e(N, 3), means2D=e(N, 3), scaling=e(N, 3), rotation=e(N, 4),
                           opacity=e(N, 1), shs=e(N, 16, 3)) for _ in range(2)]
         self._one = torch.ones(1, device=dev, dtype=f32)
-        self.r_host = torch.empty(1, dtype=i32).pin_memory()
+        self.r_host = torch.empty(3, dtype=i32).pin_memory()
         self._deform_ws = None
         self._R_last = 0
 
@@ -153,19 +153,19 @@ class ViewPipeline:
                                     ptr(self.scan_ws), acts)
         _lib.call("fdgs_raster_preprocess_fwd", pa)
         # the data-dependent list length R: one 4-byte device->host read (the step's only synchronisation)
-        self.r_host.copy_(self.point_offsets[N - 1:N], non_blocking=True)
+        self.r_host.copy_(self.scan_ws[:3], non_blocking=True)     # depth range (two words) and R
         ready = torch.cuda.Event()
         ready.record()
         if while_waiting is not None:
             while_waiting()
         ready.synchronize()
-        R = int(self.r_host[0])
+        dmin, dmax, R = (int(v) & 0xffffffff for v in self.r_host.tolist())
         _rasterizer.LAST_NUM_RENDERED = R
         self._list_buffers(max(R, 1), dev)
         _lib.call("fdgs_raster_bin_sort",
                   _lib.BinSortArgs(N, W, H, R, ptr(self.geom), ptr(self.point_offsets), ptr(self.keys_a),
                                    ptr(self.vals_a), ptr(self.keys_b), ptr(self.vals_b), ptr(self.ranges),
-                                   ptr(self.sort_ws), self.sort_ws_bytes))
+                                   ptr(self.sort_ws), self.sort_ws_bytes, dmin, dmax))
         plist = ptr(self.vals_b) if R > 0 else None
         _lib.call("fdgs_raster_blend_fwd",
                   _lib.BlendFwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.color),

@@ -102,7 +102,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
                 torch.empty(ws_bytes, device=dev, dtype=torch.uint8), ws_bytes)
     bufs = list_buffers(_LIST_CAPACITY) if _LIST_CAPACITY > 0 else None
     # the data-dependent list length R: one small device->host read (stream sync)
-    R = int(st.point_offsets[-1].item()) if N > 0 else 0
+    dmin, dmax, R = ((int(v) & 0xffffffff for v in scan_ws[:3].tolist()) if N > 0 else (0, 0, 0))
     st.num_rendered = R
     global LAST_NUM_RENDERED
     LAST_NUM_RENDERED = R
@@ -110,7 +110,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
         bufs = list_buffers(_list_capacity(max(R, 1)))
     _, keys_a, vals_a, st.keys_sorted, st.vals_sorted, sort_ws, ws_bytes = bufs
     b = _lib.BinSortArgs(N, W, H, R, ptr(st.geom), ptr(st.point_offsets), ptr(keys_a), ptr(vals_a),
-                         ptr(st.keys_sorted), ptr(st.vals_sorted), ptr(st.ranges), ptr(sort_ws), ws_bytes)
+                         ptr(st.keys_sorted), ptr(st.vals_sorted), ptr(st.ranges), ptr(sort_ws), ws_bytes, dmin, dmax)
     _lib.call("fdgs_raster_bin_sort", b)
     if not keep_keys:
         st.keys_sorted = None
