@@ -1253,6 +1253,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         WGradSK w1;
         w1.n = n;
         w1.chunks_per_block = per;
+        w1.heads_together = 0;
         for (int i = 0; i < WGS_MAX; ++i) w1.d[i].C = nullptr;
         // dW0 is 128 rows of 128 bytes: every workgroup would hit every one of them; private copies instead
         float* slab_w = ws_yfeat + (size_t)48 * ((size_t)n + 16);
@@ -1457,11 +1458,13 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                 hipLaunchKernelGGL(wgrad_prep_split_kernel, dim3(pblocks, 1), dim3(256), 0, s, pk);
                 FDGS_CHECK_LAUNCH();
             }
-            int per = (chunks + 203) / 204;     // about a thousand workgroups of four waves
+            static const int wg_ranges = getenv("FDGS_WGRAD_RANGES") ? atoi(getenv("FDGS_WGRAD_RANGES")) : 204;
+            int per = (chunks + wg_ranges - 1) / wg_ranges;     // about a thousand workgroups of four waves
             if (per < 4) per = 4;
             WGradSK w4;
             w4.n = cn;
             w4.chunks_per_block = per;
+            w4.heads_together = getenv("FDGS_WGRAD_GRID2D") ? 0 : 5;
             for (int i = 0; i < WGS_MAX; ++i) w4.d[i].C = nullptr;
             for (int h = 0; h < 5; ++h)
                 {
@@ -1477,7 +1480,9 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                         w4.d[h].C = op_q; w4.d[h].rowsum = op_q + DW * DW;
                     }
                 }
-            hipLaunchKernelGGL(deform_wgrad_split_kernel<4>, dim3((chunks + per - 1) / per, 5), dim3(256), 0, s, w4);
+            const int ranges = (chunks + per - 1) / per;
+            const dim3 grid4 = w4.heads_together ? dim3(8 * 5 * ((ranges + 7) / 8), 1) : dim3(ranges, 5);
+            hipLaunchKernelGGL(deform_wgrad_split_kernel<4>, grid4, dim3(256), 0, s, w4);
             FDGS_CHECK_LAUNCH();
             // dW2_h = g_h^T relu(h1_h) with h1 recomputed in place (nothing stored), db2_h = column sums of g_h
             WGrad2SK w2k;

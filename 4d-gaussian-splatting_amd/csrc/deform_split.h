@@ -896,21 +896,32 @@ struct WGradSDesc {
 #define WGS_MAX 6
 struct WGradSK {
     int n; int chunks_per_block;
+    // heads_together > 0: a one-dimensional grid of 8 * heads_together * ceil(ranges / 8) workgroups in which the
+    // workgroups of one point range (one per product) are consecutive multiples of 8 apart: workgroups go to the
+    // eight XCDs in turn, so these run side by side on ONE XCD and the Y pieces of the range, which all of them
+    // read, come from HBM once and from that XCD's L2 afterwards.  0: grid (ranges, products)
+    int heads_together;
     WGradSDesc d[WGS_MAX];
 };
 
 template <int NB>
 __global__ void __launch_bounds__(256)
 deform_wgrad_split_kernel(WGradSK a) {
+    int product = blockIdx.y, range = blockIdx.x;
+    if (a.heads_together > 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        product = j % a.heads_together;
+        range = (j / a.heads_together) * 8 + xcd;
+    }
     WGradSDesc d = a.d[0];
 #pragma unroll
     for (int i = 1; i < WGS_MAX; ++i)
-        if ((int)blockIdx.y == i) d = a.d[i];
+        if (product == i) d = a.d[i];
     if (!d.C) return;
     const int lane = threadIdx.x & 63, mb = threadIdx.x >> 6;
     const int c = lane & 31, g = lane >> 5;
     const int total_chunks = (a.n + 15) / 16;
-    const int ch_begin = blockIdx.x * a.chunks_per_block;
+    const int ch_begin = range * a.chunks_per_block;
     const int ch_end = min(ch_begin + a.chunks_per_block, total_chunks);
     if (ch_begin >= ch_end) return;
     floatx16 acc[NB];
@@ -1051,7 +1062,7 @@ deform_wgrad_split_kernel(WGradSK a) {
             }
         }
     }
-    const int slab = d.slabs > 1 ? (int)(blockIdx.x % (unsigned)d.slabs) : 0;
+    const int slab = d.slabs > 1 ? (int)((unsigned)range % (unsigned)d.slabs) : 0;
     float* __restrict__ Cs = d.C + (size_t)slab * d.slab_stride;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
@@ -1115,6 +1126,9 @@ struct WGrad2SK {
 // 3 + 3 + 4 + 1 rows packed into one 32-row block (row offsets 0, 3, 6, 10): the A operand of a head is zero
 // outside its rows, so the four products accumulate into the same block and the saved relu(hidden) pieces of a
 // tile are fetched from HBM once for the four heads.
+#ifndef FDGS_W2_FRAG_AHEAD
+#define FDGS_W2_FRAG_AHEAD 2
+#endif
 template <int NOB>
 __global__ void __launch_bounds__(64, 1)
 deform_wgrad2_split_kernel(WGrad2SK a) {
@@ -1157,9 +1171,10 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
             // product 1, K = 128 input features; both operands arrive as ready pieces (1 KiB coalesced loads)
             // the relu(hidden) pieces are unique to the tile (HBM latency): requested HS_AHEAD K chunks ahead
             constexpr int HS_AHEAD = 3;
-            Split3 f[3], hs[HS_AHEAD + 1][2];
-            f[0] = sfrag_load_u(pw, 0 * 8 + 0, lane);
-            f[1] = sfrag_load_u(pw, 1 * 8 + 0, lane);
+            constexpr int FA = FDGS_W2_FRAG_AHEAD;     // weight fragments requested FA steps ahead
+            Split3 f[FA + 1], hs[HS_AHEAD + 1][2];
+#pragma unroll
+            for (int t = 0; t < FA; ++t) f[t] = sfrag_load_u(pw, (t & 3) * 8 + (t >> 2), lane);
 #pragma unroll
             for (int jj = 0; jj < HS_AHEAD; ++jj)
 #pragma unroll
@@ -1167,7 +1182,7 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
 #pragma unroll
             for (int t = 0; t < 32; ++t) {
                 const int j = t >> 2, fb = t & 3;
-                if (t + 2 < 32) f[(t + 2) % 3] = sfrag_load_u(pw, ((t + 2) & 3) * 8 + ((t + 2) >> 2), lane);
+                if (t + FA < 32) f[(t + FA) % (FA + 1)] = sfrag_load_u(pw, ((t + FA) & 3) * 8 + ((t + FA) >> 2), lane);
                 if (fb == 0 && j + HS_AHEAD < 8) {
 #pragma unroll
                     for (int mb = 0; mb < 2; ++mb)
@@ -1189,7 +1204,7 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
                     }
                 }
 #pragma unroll
-                for (int mb = 0; mb < 2; ++mb) c1[mb][fb] = mma_split(hs[j % (HS_AHEAD + 1)][mb], f[t % 3], c1[mb][fb]);
+                for (int mb = 0; mb < 2; ++mb) c1[mb][fb] = mma_split(hs[j % (HS_AHEAD + 1)][mb], f[t % (FA + 1)], c1[mb][fb]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // product 2, K = the 64 points of this step: chunk (mb, jj) = points p0 + 32 mb + drow(8 jj + e, g)

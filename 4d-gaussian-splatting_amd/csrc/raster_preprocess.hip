@@ -313,31 +313,57 @@ scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// Stage 3: duplicateWithKeys.  One thread per Gaussian writes one (key,value)
-// per touched tile, tiles row-major.  key = (tile_id << 32) | bits(depth); when the
+// Stage 3: duplicateWithKeys.  Gaussian i owns the list positions [offsets[i-1], offsets[i]) and gets one
+// (key, value) pair per touched tile there, tiles row-major.  key = (tile_id << 32) | bits(depth); when the
 // frame's depth range is known, in the order-preserving compressed form
 // (tile_id << depth_bits) | (bits(depth) - depth_min), which the sort's last pass expands again.
+// A wave takes 64 consecutive Gaussians and writes their positions TOGETHER: lane l writes positions first + l,
+// first + l + 64, ... and finds the owner of each by binary search over the 64 scan values (in LDS), so every store
+// instruction covers 64 consecutive entries.  (One thread per Gaussian looping over its own tiles stores to 64
+// unrelated lines per instruction and runs as long as the wave's largest splat.)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int n, const float* __restrict__ geom, const uint32_t* __restrict__ offsets,
                            uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, int gy,
                            int depth_bits, uint32_t depth_min) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 g2 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 2];
-    const int radius = fdgs_unpack_radius(__float_as_int(g2.z));
-    if (radius <= 0) return;
-    const float4 g0 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 0];
-    uint32_t off = (i == 0) ? 0u : offsets[i - 1];
-    int x0, y0, x1, y1;
-    fdgs_tile_rect(g0.x, g0.y, (float)radius, gx, gy, x0, y0, x1, y1);
-    const uint64_t dbits = (uint64_t)(__float_as_uint(g2.y) - depth_min);
-    for (int ty = y0; ty < y1; ++ty)
-        for (int tx = x0; tx < x1; ++tx) {
-            keys[off] = ((uint64_t)(uint32_t)(ty * gx + tx) << depth_bits) | dbits;
-            vals[off] = (uint32_t)i;
-            ++off;
-        }
+    __shared__ uint32_t s_end[4][64], s_start[4][64], s_x0w[4][64], s_y0[4][64], s_depth[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int ic = i < n ? i : n - 1;
+    const uint32_t end = offsets[ic];
+    const uint32_t start = i < n ? (i == 0 ? 0u : offsets[i - 1]) : end;
+    uint32_t x0w = 0, y0v = 0, dbits = 0;
+    if (end > start) {
+        const float4 g2 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 2];
+        const int radius = fdgs_unpack_radius(__float_as_int(g2.z));
+        const float4 g0 = reinterpret_cast<const float4*>(geom)[3 * (size_t)i + 0];
+        int x0, y0, x1, y1;
+        fdgs_tile_rect(g0.x, g0.y, (float)radius, gx, gy, x0, y0, x1, y1);
+        x0w = (uint32_t)x0 | ((uint32_t)(x1 - x0) << 16);
+        y0v = (uint32_t)y0;
+        dbits = __float_as_uint(g2.y) - depth_min;
+    }
+    s_end[wave][lane] = end;
+    s_start[wave][lane] = start;
+    s_x0w[wave][lane] = x0w;
+    s_y0[wave][lane] = y0v;
+    s_depth[wave][lane] = dbits;
+    __syncthreads();
+    const uint32_t first = s_start[wave][0], last = s_end[wave][63];
+    const uint32_t i0 = (uint32_t)(blockIdx.x * 256 + wave * 64);
+    for (uint32_t pos = first + lane; pos < last; pos += 64) {
+        int l = 0;                                  // the first Gaussian of the wave whose end lies beyond pos
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1)
+            if (s_end[wave][l + step - 1] <= pos) l += step;
+        const uint32_t q = pos - s_start[wave][l];
+        const uint32_t xw = s_x0w[wave][l];
+        const uint32_t w = xw >> 16;
+        const uint32_t row = q / w;
+        const uint32_t tile = (s_y0[wave][l] + row) * (uint32_t)gx + (xw & 0xffffu) + (q - row * w);
+        keys[pos] = ((uint64_t)tile << depth_bits) | (uint64_t)s_depth[wave][l];
+        vals[pos] = i0 + (uint32_t)l;
+    }
 }
 
 // ---------------------------------------------------------------------------
