@@ -938,9 +938,11 @@ deform_wgrad_split_kernel(WGradSK a) {
     constexpr int XA = 4;
     __shared__ u32x4 ybuf[2][4 * 3 * 64];
     // on-the-fly X: per wave, the 16 x k cotangents and the 32 mask words of a chunk pass through LDS so that
-    // every lane can read those of its eight points (broadcast reads)
-    __shared__ float fly_cot[4][64];
-    __shared__ unsigned fly_msk[4][32];
+    // every lane can read those of its eight points (broadcast reads).  They are staged TRANSPOSED - cotangent
+    // (point, o) at o * 16 + point, mask word (point, lane half) at half * 16 + point - so that a lane's eight points
+    // are eight consecutive words: two 16-byte reads per output and per mask instead of eight 4-byte ones.
+    __shared__ __align__(16) float fly_cot[4][64];
+    __shared__ __align__(16) unsigned fly_msk[4][32];
     const bool fly = d.cot != nullptr;
     float cotr[XA];
     unsigned mskr[XA];
@@ -954,6 +956,12 @@ deform_wgrad_split_kernel(WGradSK a) {
     // with r = (c & 3) + 4 ((c >> 3) & 3)
     const int fly_half = (c >> 2) & 1;
     const int fly_bit = 31 - (16 * (mb & 1) + (c & 3) + 4 * ((c >> 3) & 3));
+    // staging slots of the words this lane loads: cotangent word `lane` is (point lane / k, output lane % k), mask
+    // word `lane` (< 32) is (point lane >> 1, lane half lane & 1); lanes beyond 16 k hold zeros and keep slot `lane`,
+    // which no reader uses (readers touch slots below 16 k)
+    int cot_slot = lane;
+    if (fly && lane < 16 * d.k) cot_slot = (lane % d.k) * 16 + lane / d.k;
+    const int msk_slot = ((lane & 1) << 4) | ((lane >> 1) & 15);
     auto load_fly = [&](int ch, float& co, unsigned& mo) {
         const int pb = ch * 16;
         co = 0.0f; mo = 0u;
@@ -994,36 +1002,38 @@ deform_wgrad_split_kernel(WGradSK a) {
     // X of chunk `ch` as split operand pieces, from ring stage i (static); refills the stage for chunk ch + XA.
     // It is called for the NEXT chunk right after the current chunk's MFMAs are issued, so that its vector and
     // LDS work runs under the matrix pipeline.
-    auto fly_point = [&](auto kc, int pt) -> float {       // kc: the head's output count as a compile-time value
+    auto fly_x = [&](auto kc, float* xv) {                 // kc: the head's output count as a compile-time value
         constexpr int K = decltype(kc)::value;
-        float cv[K];
+        const float4* cq = reinterpret_cast<const float4*>(&fly_cot[mb][0]) + 2 * g;
+        const uint4* mq = reinterpret_cast<const uint4*>(&fly_msk[mb][0]) + 4 * fly_half + 2 * g;
+        float x[8];
 #pragma unroll
-        for (int o = 0; o < K; ++o) cv[o] = fly_cot[mb][pt * K + o];
-        float x = 0.0f;
+        for (int e = 0; e < 8; ++e) x[e] = 0.0f;
 #pragma unroll
-        for (int o = 0; o < K; ++o) x = fmaf(w2v[o], cv[o], x);
-        const int masked = __builtin_amdgcn_sbfe((int)fly_msk[mb][pt * 2 + fly_half], fly_bit, 1);
-        return __uint_as_float(__float_as_uint(x) & ~(unsigned)masked);
+        for (int o = 0; o < K; ++o) {
+            const float4 lo = cq[4 * o], hi = cq[4 * o + 1];
+            const float cv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = fmaf(w2v[o], cv[e], x[e]);
+        }
+        const uint4 mlo = mq[0], mhi = mq[1];
+        const unsigned mw[8] = {mlo.x, mlo.y, mlo.z, mlo.w, mhi.x, mhi.y, mhi.z, mhi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int masked = __builtin_amdgcn_sbfe((int)mw[e], fly_bit, 1);
+            xv[e] = __uint_as_float(__float_as_uint(x[e]) & ~(unsigned)masked);
+        }
     };
     auto make_x = [&](int ch, int i) -> Split3 {
         float xv[8];
         if (fly) {
-            fly_cot[mb][lane] = cotr[i];
-            if (lane < 32) fly_msk[mb][lane] = mskr[i];
+            fly_cot[mb][cot_slot] = cotr[i];
+            if (lane < 32) fly_msk[mb][msk_slot] = mskr[i];
             if (ch + XA < ch_end) load_fly(ch + XA, cotr[i], mskr[i]);
-            if (d.k == 4) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = fly_point(std::integral_constant<int, 4>{}, 8 * g + e);
-            } else if (d.k == 3) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = fly_point(std::integral_constant<int, 3>{}, 8 * g + e);
-            } else if (d.k == 2) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = fly_point(std::integral_constant<int, 2>{}, 8 * g + e);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xv[e] = fly_point(std::integral_constant<int, 1>{}, 8 * g + e);
-            }
+            if (d.k == 4) fly_x(std::integral_constant<int, 4>{}, xv);
+            else if (d.k == 3) fly_x(std::integral_constant<int, 3>{}, xv);
+            else if (d.k == 2) fly_x(std::integral_constant<int, 2>{}, xv);
+            else fly_x(std::integral_constant<int, 1>{}, xv);
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) xv[e] = xr[i][e];
