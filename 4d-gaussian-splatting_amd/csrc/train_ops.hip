@@ -29,7 +29,10 @@ l1_partial_kernel(fdgs_l1_fwd_args a) {
     const long long per_block = (long long)L1_THREADS * L1_PER_THREAD;
     const long long base = (long long)blockIdx.x * per_block;
     float s = 0.0f, q = 0.0f;
-    const bool vec = ((((size_t)a.a | (size_t)a.b) & 15) == 0) && base + per_block <= a.n;
+    // optional gradient for an upstream gradient of 1, the expression of l1_bwd_kernel
+    const float g = (float)((double)a.scale / (double)a.n);
+    auto sgn = [g](float d) { return d > 0.0f ? g : (d < 0.0f ? -g : 0.0f * d); };
+    const bool vec = ((((size_t)a.a | (size_t)a.b | (size_t)a.grad_a) & 15) == 0) && base + per_block <= a.n;
     if (vec) {
 #pragma unroll
         for (int u = 0; u < L1_PER_THREAD / 4; ++u) {
@@ -38,12 +41,14 @@ l1_partial_kernel(fdgs_l1_fwd_args a) {
             const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
             s += (fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3));
             q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            if (a.grad_a) *reinterpret_cast<float4*>(a.grad_a + i) = make_float4(sgn(d0), sgn(d1), sgn(d2), sgn(d3));
         }
     } else {
         for (long long i = base + threadIdx.x; i < base + per_block && i < a.n; i += L1_THREADS) {
             const float d = a.a[i] - a.b[i];
             s += fabsf(d);
             q += d * d;
+            if (a.grad_a) a.grad_a[i] = sgn(d);
         }
     }
     s = block_sum_256(s, sh);

@@ -171,9 +171,9 @@ class ViewPipeline:
                   _lib.BlendFwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.color),
                                     ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib)))
         n_img = 3 * H * W
+        # the view's loss is this term alone: its gradient comes out of the same pass over the two images
         _lib.call("fdgs_l1_loss_fwd", _lib.L1FwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(self.loss),
-                                                     ptr(self.l1_partial), ptr(self.psnr) if want_psnr else None))
-        _lib.call("fdgs_l1_loss_bwd", _lib.L1BwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(self._one),
+                                                     ptr(self.l1_partial), ptr(self.psnr) if want_psnr else None,
                                                      ptr(self.grad_image)))
         _lib.call("fdgs_raster_blend_bwd",      # dgeom: zero from its allocation, re-zeroed by preprocess_bwd below
                   _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),

@@ -324,7 +324,8 @@ size_t fdgs_hexplane_features_workspace_bytes(const fdgs_deform_params* p, int32
 int fdgs_hexplane_features(const fdgs_hexplane_features_args* a, void* stream);
 
 /* ---- L1 image loss: scale * mean |a - b| over n floats (src/model/losses.py:7-8, called at
- * src/runner/fdgs_trainer.py:495) and its gradient w.r.t. a.  Two launches forward, one backward. */
+ * src/runner/fdgs_trainer.py:495) and its gradient w.r.t. a.  Two launches forward (the first can write the
+ * gradient for an upstream gradient of 1 as well), one backward. */
 typedef struct {
     int64_t n;
     const float* a;                  /* [n] rendered image(s)                       */
@@ -335,6 +336,9 @@ typedef struct {
     float* psnr;                     /* NULL, or [1]: 20 log10(1 / sqrt(mean (a-b)^2)) of the same n elements -
                                         the per-iteration metric of src/model/metrics.py:7-28 (fdgs_trainer.py:131)
                                         from the same pass over the two images */
+    float* grad_a;                   /* NULL, or [n]: d(loss)/da = scale / n * sign(a - b), what fdgs_l1_loss_bwd
+                                        writes for grad_loss = 1 - for a caller whose loss IS this term (the
+                                        training step: one pass over the two images instead of two) */
 } fdgs_l1_fwd_args;
 typedef struct {
     int64_t n;

@@ -179,3 +179,35 @@ def test_train_step_with_ssim_term_and_psnr():
     for v in range(2):
         errs = [float((gk - want_dimg[v]).abs().max()) for gk in seen]
         assert min(errs) <= 5e-4 * float(want_dimg[v].abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [3 * 1014 * 1352, 4096 * 3 + 17, 5])
+def test_l1_forward_writes_the_gradient_of_the_backward_call(n):
+    """fdgs_l1_loss_fwd with grad_a set: the same values as fdgs_l1_loss_bwd with an upstream gradient of 1 (bit
+    for bit), loss and PSNR unchanged; full image size, a ragged tail and fewer elements than one vector."""
+    from fdgs import _lib
+    from fdgs._lib import lib, ptr
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(n)
+    a = torch.rand(n, generator=gen).to(dev)
+    b = torch.rand(n, generator=gen).to(dev)
+    b[::7] = a[::7]                                   # exact zeros of the difference
+    scale = 0.125
+    partial = torch.empty(2 * lib.fdgs_l1_loss_partials(n), device=dev)
+    out = {}
+    for tag, with_grad in (("plain", False), ("fused", True)):
+        loss, ps = torch.empty((), device=dev), torch.empty((), device=dev)
+        grad = torch.full((n,), float("nan"), device=dev)
+        _lib.call("fdgs_l1_loss_fwd", _lib.L1FwdArgs(n, ptr(a), ptr(b), scale, ptr(loss), ptr(partial), ptr(ps),
+                                                     ptr(grad) if with_grad else None))
+        out[tag] = (loss.clone(), ps.clone(), grad)
+    one = torch.ones(1, device=dev)
+    ref = torch.empty(n, device=dev)
+    _lib.call("fdgs_l1_loss_bwd", _lib.L1BwdArgs(n, ptr(a), ptr(b), scale, ptr(one), ptr(ref)))
+    torch.cuda.synchronize()
+    assert torch.equal(out["fused"][2], ref)
+    assert torch.equal(out["fused"][0], out["plain"][0]) and torch.equal(out["fused"][1], out["plain"][1])
+    assert torch.isnan(out["plain"][2]).all()         # not touched without the pointer
+    expect = (scale / n) * torch.sign(a.double() - b.double())
+    assert float((ref.double() - expect).abs().max()) <= 1e-6 * scale / n
