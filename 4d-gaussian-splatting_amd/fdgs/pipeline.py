@@ -64,8 +64,10 @@ class ViewPipeline:
         self.n_contrib = e(H, W, dtype=i32)
         self.ranges = e(gx * gy, 2, dtype=i32)
         n_img = 3 * H * W
-        self.loss = e(())
-        self.psnr = e(())
+        # loss and PSNR scalars: two of each, used in turn, so that the values of a view stay readable while the
+        # next view (or the next step's) is computed
+        self._scalars = [(e(()), e(())), (e(()), e(()))]
+        self._scalar_turn = 0
         self.l1_partial = e(2 * lib.fdgs_l1_loss_partials(n_img))
         self.grad_image = e(3, H, W)
         # backward; two sets of per-Gaussian gradient buffers so that a second view can be added to the first
@@ -172,8 +174,10 @@ class ViewPipeline:
                                     ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib)))
         n_img = 3 * H * W
         # the view's loss is this term alone: its gradient comes out of the same pass over the two images
-        _lib.call("fdgs_l1_loss_fwd", _lib.L1FwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(self.loss),
-                                                     ptr(self.l1_partial), ptr(self.psnr) if want_psnr else None,
+        self._scalar_turn ^= 1
+        loss_buf, psnr_buf = self._scalars[self._scalar_turn]
+        _lib.call("fdgs_l1_loss_fwd", _lib.L1FwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(loss_buf),
+                                                     ptr(self.l1_partial), ptr(psnr_buf) if want_psnr else None,
                                                      ptr(self.grad_image)))
         _lib.call("fdgs_raster_blend_bwd",      # dgeom: zero from its allocation, re-zeroed by preprocess_bwd below
                   _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),
@@ -202,5 +206,5 @@ class ViewPipeline:
                 pending.wait()
         out.xyz, out.scaling, out.rotation, out.opacity = S["xyz"], S["scaling"], S["rotation"], S["opacity"]
         out.shs, out.means2D, out.radii = g_sh, S["means2D"], self.radii
-        out.loss, out.psnr = self.loss, (self.psnr if want_psnr else None)
+        out.loss, out.psnr = loss_buf, (psnr_buf if want_psnr else None)
         return out

@@ -127,8 +127,9 @@ class TrainStep:
         for i, cam in enumerate(views):
             vg = self.pipeline.run(cam, cam.original_image, scale, self.stage, grad_set=min(i, 1), deform_grads=dgrads,
                                    sh_hook=hook if fine else None, while_waiting=while_waiting if i == 0 else None)
-            loss = vg.loss.clone() if loss is None else loss + vg.loss
-            psnr_sum = vg.psnr.clone() if psnr_sum is None else psnr_sum + vg.psnr
+            # a view's scalars live in one of the pipeline's two buffers, valid until the view after the next
+            loss = vg.loss if loss is None else loss + vg.loss
+            psnr_sum = vg.psnr if psnr_sum is None else psnr_sum + vg.psnr
             if i == 0:
                 acc = vg
                 radii = vg.radii if len(views) == 1 else vg.radii.clone()
@@ -139,7 +140,7 @@ class TrainStep:
         self.last_psnr = psnr_sum / len(views) if len(views) > 1 else psnr_sum
         g._xyz.grad, g._scaling.grad, g._rotation.grad, g._opacity.grad = acc.xyz, acc.scaling, acc.rotation, acc.opacity
         g._features_dc.grad, g._features_rest.grad = acc.shs[:, :1, :], acc.shs[:, 1:, :]
-        return loss, radii, radii > 0, acc.means2D
+        return loss, radii, None, acc.means2D      # visibility = radii > 0 where a caller needs it
 
     def _views_autograd(self, views, scale, hook):
         """render() + autograd: the reference's interface (any activation callables, SSIM term)."""
@@ -180,7 +181,9 @@ class TrainStep:
         return self.regulation_weights if "fine" in self.stage else None
 
     def __call__(self, global_views, iteration=None, stage=None, before_optimizer_step=None):
-        """global_views: the whole batch (identical on every rank); returns the local loss value tensor.
+        """global_views: the whole batch (identical on every rank); returns the local loss value tensor (with one
+        local view on the direct route it is one of two device scalars used in turn: read it, or copy it, before
+        the step after the next; `last_psnr` likewise).
         iteration: the trainer's counter; when given, the scheduled learning rates are set first
         (fdgs_trainer.py:216, 288-302).
         stage: "coarse" / "fine" for this and the following calls (fdgs_trainer.py:114); None keeps the last one.

@@ -519,7 +519,7 @@ def main():
         out["roofline_hbm_calls"] = [
             hbm("fdgs_raster_preprocess_bwd", 40.0 * V + 236.0 * N + 248.0 * N),
             hbm("fdgs_adam_step", 28.0 * n_param),
-            hbm("fdgs_l1_loss_bwd", 12.0 * 3 * px),
+            hbm("fdgs_l1_loss_fwd", 12.0 * 3 * px),     # two images read, the gradient image written
             hbm("fdgs_raster_blend_fwd", 44.0 * R + 28.0 * px),
             hbm("fdgs_raster_bin_sort", 24.0 * V + 12.0 * R + 24.0 * R + 8.0 * R),
         ]
