@@ -71,7 +71,10 @@ l1_final_kernel(fdgs_l1_fwd_args a, int num_partials) {
         if ((int)threadIdx.x < o) shd[threadIdx.x] += shd[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) a.loss[0] = (float)(shd[0] / (double)a.n * (double)a.scale);
+    if (threadIdx.x == 0) {
+        const float l1 = (float)(shd[0] / (double)a.n * (double)a.scale);
+        a.loss[0] = a.add ? l1 + a.add[0] : l1;
+    }
     if (a.psnr) {
         __syncthreads();
         double q = 0.0;

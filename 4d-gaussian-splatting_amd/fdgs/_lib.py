@@ -108,7 +108,7 @@ class HexFeaturesArgs(C.Structure):
 
 class L1FwdArgs(C.Structure):
     _fields_ = [("n", c_i64), ("a", c_p), ("b", c_p), ("scale", c_f), ("loss", c_p), ("partial", c_p), ("psnr", c_p),
-                ("grad_a", c_p)]
+                ("grad_a", c_p), ("add", c_p)]
 
 
 class L1BwdArgs(C.Structure):
@@ -227,7 +227,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 
 def _load():

@@ -110,7 +110,8 @@ class ViewPipeline:
         the order of fdgs.deformation._trainable, accumulated into (fine stage).  Returns a ViewGrads whose tensors
         are this object's buffers of set `grad_set` (valid until that set is used again).  while_waiting: callable
         run after the tile-list length has been requested from the device and before the host waits for it - work
-        enqueued there (anything that does not depend on this view) runs while that 4-byte read is in flight."""
+        enqueued there (anything that does not depend on this view) runs while that 4-byte read is in flight; it may
+        return a device scalar (float32) that is added to this view's loss value."""
         g = self.g
         xyz = g._xyz.detach()
         dev = xyz.device
@@ -158,8 +159,7 @@ class ViewPipeline:
         self.r_host.copy_(self.scan_ws[:3], non_blocking=True)     # depth range (two words) and R
         ready = torch.cuda.Event()
         ready.record()
-        if while_waiting is not None:
-            while_waiting()
+        loss_term = while_waiting() if while_waiting is not None else None
         ready.synchronize()
         dmin, dmax, R = (int(v) & 0xffffffff for v in self.r_host.tolist())
         _rasterizer.LAST_NUM_RENDERED = R
@@ -178,7 +178,7 @@ class ViewPipeline:
         loss_buf, psnr_buf = self._scalars[self._scalar_turn]
         _lib.call("fdgs_l1_loss_fwd", _lib.L1FwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(loss_buf),
                                                      ptr(self.l1_partial), ptr(psnr_buf) if want_psnr else None,
-                                                     ptr(self.grad_image)))
+                                                     ptr(self.grad_image), ptr(loss_term)))
         _lib.call("fdgs_raster_blend_bwd",      # dgeom: zero from its allocation, re-zeroed by preprocess_bwd below
                   _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),
                                     ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom)))

@@ -119,9 +119,8 @@ class TrainStep:
                     dgrads[i] = piece.view(shape)
                 self._dflat = (flat, dgrads)
             flat, dgrads = self._dflat
-            flat.zero_()
-            for p, gr in zip(params, dgrads):     # attached now: the regulariser may add to them before the first
-                p.grad = gr                        # view's backward does
+            for p, gr in zip(params, dgrads):     # attached now: the regulariser adds to them before the first
+                p.grad = gr                        # view's backward does; zeroed where the regulariser runs
         loss = psnr_sum = radii = None
         acc = None
         for i, cam in enumerate(views):
@@ -225,12 +224,16 @@ class TrainStep:
             # waits for the tile-list length and the GPU would otherwise idle
             box = {}
 
-            def regulariser():
+            def regulariser():      # runs inside the first view's forward: returns the term to add to its loss value
+                if self._dflat is not None and "fine" in self.stage:
+                    self._dflat[0].zero_()      # the deformation gradients of this step start here
                 if reg_w is not None:
                     box["reg"] = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
+                    return box["reg"]
+                return None
             loss, radii, vis, vgrad = self._views_direct(views, scale, hook, regulariser if views else None)
-            if "reg" in box:
-                reg, reg_w = box["reg"], None
+            if "reg" in box:        # already inside `loss` (added on the device by the first view's loss kernel)
+                reg, reg_w = None, None
         else:
             loss, radii, vis, vgrad = self._views_autograd(views, scale, hook)
         if reg_w is not None:

@@ -339,6 +339,9 @@ typedef struct {
     float* grad_a;                   /* NULL, or [n]: d(loss)/da = scale / n * sign(a - b), what fdgs_l1_loss_bwd
                                         writes for grad_loss = 1 - for a caller whose loss IS this term (the
                                         training step: one pass over the two images instead of two) */
+    const float* add;                /* NULL, or [1]: a device scalar added to the loss value (a term of the training
+                                        loss computed elsewhere, e.g. the grid regulariser of fdgs_plane_regulation);
+                                        it does not enter grad_a or psnr */
 } fdgs_l1_fwd_args;
 typedef struct {
     int64_t n;
