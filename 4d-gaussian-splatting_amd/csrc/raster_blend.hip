@@ -92,7 +92,8 @@ __device__ __forceinline__ void reach4(float gx, float gy, uint32_t reach, float
 
 __global__ void __launch_bounds__(256)
 blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
-    const int tile = blockIdx.x;
+    const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
+    if ((unsigned)tile >= gridDim.x) return;        // not a tile id: the caller's tile_order is not a permutation
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane >> 4, li = lane & 15;
@@ -207,7 +208,8 @@ __device__ __forceinline__ float fold2(float x, float y, bool upper) {
 
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
-    const int tile = blockIdx.x;
+    const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
+    if ((unsigned)tile >= gridDim.x) return;        // not a tile id: the caller's tile_order is not a permutation
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane >> 4, li = lane & 15;

@@ -38,19 +38,19 @@ class BinSortArgs(C.Structure):
                 ("geom", c_p), ("point_offsets", c_p),
                 ("keys_unsorted", c_p), ("vals_unsorted", c_p), ("keys_sorted", c_p), ("vals_sorted", c_p),
                 ("ranges", c_p), ("sort_workspace", c_p), ("sort_workspace_bytes", c_sz),
-                ("depth_bits_min", C.c_uint32), ("depth_bits_max", C.c_uint32)]
+                ("depth_bits_min", C.c_uint32), ("depth_bits_max", C.c_uint32), ("tile_order", c_p)]
 
 
 class BlendFwdArgs(C.Structure):
     _fields_ = [("image_width", c_i32), ("image_height", c_i32),
                 ("ranges", c_p), ("point_list", c_p), ("geom", c_p), ("bg", c_p),
-                ("out_color", c_p), ("out_depth", c_p), ("final_T", c_p), ("n_contrib", c_p)]
+                ("out_color", c_p), ("out_depth", c_p), ("final_T", c_p), ("n_contrib", c_p), ("tile_order", c_p)]
 
 
 class BlendBwdArgs(C.Structure):
     _fields_ = [("image_width", c_i32), ("image_height", c_i32),
                 ("ranges", c_p), ("point_list", c_p), ("geom", c_p), ("bg", c_p),
-                ("final_T", c_p), ("n_contrib", c_p), ("dL_dcolor", c_p), ("dL_dgeom", c_p)]
+                ("final_T", c_p), ("n_contrib", c_p), ("dL_dcolor", c_p), ("dL_dgeom", c_p), ("tile_order", c_p)]
 
 
 class PreprocessBwdArgs(C.Structure):
@@ -227,7 +227,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 def _load():

@@ -11,6 +11,7 @@ for the caller to attach to the parameters.
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -63,6 +64,8 @@ class ViewPipeline:
         self.final_T = e(H, W)
         self.n_contrib = e(H, W, dtype=i32)
         self.ranges = e(gx * gy, 2, dtype=i32)
+        # tiles by decreasing list length: the blend launches' order (FDGS_TILE_ORDER=0: image order)
+        self.tile_order = e(gx * gy, dtype=i32) if os.environ.get("FDGS_TILE_ORDER", "1") != "0" else None
         n_img = 3 * H * W
         # loss and PSNR scalars: two of each, used in turn, so that the values of a view stay readable while the
         # next view (or the next step's) is computed
@@ -167,11 +170,11 @@ class ViewPipeline:
         _lib.call("fdgs_raster_bin_sort",
                   _lib.BinSortArgs(N, W, H, R, ptr(self.geom), ptr(self.point_offsets), ptr(self.keys_a),
                                    ptr(self.vals_a), ptr(self.keys_b), ptr(self.vals_b), ptr(self.ranges),
-                                   ptr(self.sort_ws), self.sort_ws_bytes, dmin, dmax))
+                                   ptr(self.sort_ws), self.sort_ws_bytes, dmin, dmax, ptr(self.tile_order)))
         plist = ptr(self.vals_b) if R > 0 else None
         _lib.call("fdgs_raster_blend_fwd",
                   _lib.BlendFwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.color),
-                                    ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib)))
+                                    ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib), ptr(self.tile_order)))
         n_img = 3 * H * W
         # the view's loss is this term alone: its gradient comes out of the same pass over the two images
         self._scalar_turn ^= 1
@@ -181,7 +184,8 @@ class ViewPipeline:
                                                      ptr(self.grad_image), ptr(loss_term)))
         _lib.call("fdgs_raster_blend_bwd",      # dgeom: zero from its allocation, re-zeroed by preprocess_bwd below
                   _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),
-                                    ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom)))
+                                    ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom),
+                                    ptr(self.tile_order)))
         d_m3 = S["means3D"] if fine else S["xyz"]
         _lib.call("fdgs_raster_preprocess_bwd",
                   _lib.PreprocessBwdArgs(N, sh_degree, W, H, tanx, tany, 1.0, ptr(vm), ptr(pm), ptr(cp), ptr(m3),

@@ -59,7 +59,7 @@ def _f32c(t):
 class RasterState:
     """Device buffers produced by the forward stages (kept for backward / inspection)."""
     __slots__ = ("geom", "radii", "tiles_touched", "point_offsets", "num_rendered", "keys_sorted", "vals_sorted",
-                 "ranges", "final_T", "n_contrib", "color", "depth", "cam")
+                 "ranges", "tile_order", "final_T", "n_contrib", "color", "depth", "cam")
 
 
 def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=False, colors_precomp=None,
@@ -94,6 +94,7 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     st.final_T = torch.empty(H, W, device=dev, dtype=torch.float32)
     st.n_contrib = torch.empty(H, W, device=dev, dtype=torch.int32)
     st.ranges = torch.empty(gx * gy, 2, device=dev, dtype=torch.int32)
+    st.tile_order = torch.empty(gx * gy, device=dev, dtype=torch.int32)     # tiles by decreasing list length
     # ... the R-sized ones too, at the capacity of the previous calls (redone below in the rare case R outgrew it)
     def list_buffers(cap):
         ws_bytes = lib.fdgs_raster_sort_workspace_bytes(cap)
@@ -110,14 +111,15 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
         bufs = list_buffers(_list_capacity(max(R, 1)))
     _, keys_a, vals_a, st.keys_sorted, st.vals_sorted, sort_ws, ws_bytes = bufs
     b = _lib.BinSortArgs(N, W, H, R, ptr(st.geom), ptr(st.point_offsets), ptr(keys_a), ptr(vals_a),
-                         ptr(st.keys_sorted), ptr(st.vals_sorted), ptr(st.ranges), ptr(sort_ws), ws_bytes, dmin, dmax)
+                         ptr(st.keys_sorted), ptr(st.vals_sorted), ptr(st.ranges), ptr(sort_ws), ws_bytes, dmin, dmax,
+                         ptr(st.tile_order))
     _lib.call("fdgs_raster_bin_sort", b)
     if not keep_keys:
         st.keys_sorted = None
 
     # no list entries: the list pointer is NULL (the library then also accepts the NULL geom of an empty scene)
     c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted) if R > 0 else None, ptr(st.geom), ptr(bg), ptr(st.color),
-                          ptr(st.depth), ptr(st.final_T), ptr(st.n_contrib))
+                          ptr(st.depth), ptr(st.final_T), ptr(st.n_contrib), ptr(st.tile_order))
     _lib.call("fdgs_raster_blend_fwd", c)
     return st
 
@@ -131,7 +133,7 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, color
     dgeom = torch.zeros(N, _lib.GEOM_FLOATS, device=dev, dtype=torch.float32)
     gc = _f32c(grad_color)
     a = _lib.BlendBwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted) if st.num_rendered > 0 else None, ptr(st.geom), ptr(bg), ptr(st.final_T),
-                          ptr(st.n_contrib), ptr(gc), ptr(dgeom))
+                          ptr(st.n_contrib), ptr(gc), ptr(dgeom), ptr(st.tile_order))
     _lib.call("fdgs_raster_blend_bwd", a)
     d_means3D = torch.empty(N, 3, device=dev, dtype=torch.float32)
     d_means2D = torch.empty(N, 3, device=dev, dtype=torch.float32)

@@ -125,6 +125,10 @@ typedef struct {
      * the same order on fewer digits (four passes instead of five at 1352 x 1014 for any depth range within a
      * factor of 2^16).  Both 0: unknown, all 32 depth bits are sorted.  The outputs are the same either way.       */
     uint32_t depth_bits_min, depth_bits_max;
+    /* Optional output [tiles]: the tile ids ordered by decreasing list length (to about 6 %: a counting sort on a
+     * logarithmic scale of the lengths; the order among tiles of one class is not defined), for the tile_order
+     * argument of the blend calls.  Always a permutation of 0 .. tiles-1, also when R is 0.                   */
+    uint32_t* tile_order;
 } fdgs_binsort_args;
 
 size_t fdgs_raster_sort_workspace_bytes(int64_t num_rendered);
@@ -142,6 +146,8 @@ typedef struct {
     float* out_depth;                /* [1,H,W]  sum depth_i alpha_i T_i            */
     float* final_T;                  /* [H,W]                                       */
     uint32_t* n_contrib;             /* [H,W] 1-based list position of the last contributor */
+    const uint32_t* tile_order;      /* NULL, or [tiles]: a permutation of the tile ids; workgroup i takes tile
+                                        tile_order[i] (longest lists first shortens the tail of the launch) */
 } fdgs_blend_fwd_args;
 
 int fdgs_raster_blend_fwd(const fdgs_blend_fwd_args* a, void* stream);
@@ -162,6 +168,7 @@ typedef struct {
      *   [0] log2(e) dL/dx_pix [1] log2(e) dL/dy_pix [2] -2 dL/dA [3] -dL/dB [4] -2 dL/dC [5] dL/dopacity
      *   [6..8] dL/drgb  [9..11] unused                                            */
     float* dL_dgeom;
+    const uint32_t* tile_order;      /* as in fdgs_blend_fwd_args */
 } fdgs_blend_bwd_args;
 
 int fdgs_raster_blend_bwd(const fdgs_blend_bwd_args* a, void* stream);

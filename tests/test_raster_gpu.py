@@ -55,6 +55,11 @@ def test_forward_stages(name):
     assert torch.equal(st.keys_sorted[:R].cpu(), aux["sorted_keys"])
     assert torch.equal(st.vals_sorted[:R].cpu(), aux["sorted_vals"])
     assert torch.equal(st.ranges.cpu(), aux["ranges"])
+    # the launch order of the blend kernels: a permutation of the tiles, longest lists first (to one length class)
+    order = st.tile_order.cpu().long()
+    assert torch.equal(torch.sort(order)[0], torch.arange(order.numel()))
+    lens = (aux["ranges"][:, 1] - aux["ranges"][:, 0]).long()[order]
+    assert bool((lens[1:].float() <= lens[:-1].float() * 1.07 + 1).all())
     # stage 6
     assert torch.equal(st.n_contrib.cpu(), aux["n_contrib"])
     assert float((st.final_T.cpu() - aux["final_T"]).abs().max()) <= IMG_TOL
@@ -354,3 +359,33 @@ def test_distCUDA2_matches_all_pairs_search():
     assert got.shape == (3001,)
     assert float((got.double() - ref).abs().max() / ref.max()) <= 1e-6
     assert float(got[7]) <= 1e-6 * float(ref.max()) + float(ref[7]) * 1.001 and float(ref[7]) > 0   # two zeros + one real
+
+
+def test_blend_results_do_not_depend_on_the_tile_order():
+    """fdgs_raster_blend_fwd with the tiles taken longest list first, in index order (NULL) and in reverse: the same
+    image, depth, transmittance and contributor counts bit for bit (a tile's pixels are computed by one workgroup
+    whichever it is); an array that is not a permutation is refused tile by tile instead of written through."""
+    from fdgs import _lib, rasterizer as fr
+    from fdgs._lib import ptr
+    c = rc.make_case("medium")
+    dev = torch.device("cuda:0")
+    S = _to_dev(c["S"], dev)
+    st = fr.rasterize_forward(c["means3D"].to(dev), c["shs"].to(dev), c["opacities"].reshape(-1).to(dev).contiguous(),
+                              c["scales"].to(dev), c["rotations"].to(dev), S)
+    H, W = int(S.image_height), int(S.image_width)
+    bg = st.cam[3]
+    tiles = st.ranges.shape[0]
+    ref = (st.color.clone(), st.depth.clone(), st.final_T.clone(), st.n_contrib.clone())
+    reverse = torch.arange(tiles - 1, -1, -1, device=dev, dtype=torch.int32)
+    bogus = torch.full((tiles,), tiles + 5, device=dev, dtype=torch.int32)
+    for order in (None, reverse, bogus):
+        out = [torch.full_like(t, 7) for t in ref]
+        _lib.call("fdgs_raster_blend_fwd", _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted), ptr(st.geom),
+                                                             ptr(bg), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
+                                                             ptr(order)))
+        torch.cuda.synchronize()
+        for got, want in zip(out, ref):
+            if order is bogus:
+                assert bool((got == 7).all())           # nothing written
+            else:
+                assert torch.equal(got, want)
