@@ -163,14 +163,22 @@ class ViewPipeline:
         ready = torch.cuda.Event()
         ready.record()
         loss_term = while_waiting() if while_waiting is not None else None
+
+        def binsort_args():
+            return _lib.BinSortArgs(N, W, H, 0, ptr(self.geom), ptr(self.point_offsets), ptr(self.keys_a),
+                                    ptr(self.vals_a), ptr(self.keys_b), ptr(self.vals_b), ptr(self.ranges),
+                                    ptr(self.sort_ws), self.sort_ws_bytes, 0, 0, ptr(self.tile_order))
+        # everything the host can do before it knows R is done before it waits: the GPU idles from the end of the
+        # scan until the first launch after the wait
+        bs = binsort_args() if self.capacity > 0 else None
         ready.synchronize()
         dmin, dmax, R = (int(v) & 0xffffffff for v in self.r_host.tolist())
         _rasterizer.LAST_NUM_RENDERED = R
-        self._list_buffers(max(R, 1), dev)
-        _lib.call("fdgs_raster_bin_sort",
-                  _lib.BinSortArgs(N, W, H, R, ptr(self.geom), ptr(self.point_offsets), ptr(self.keys_a),
-                                   ptr(self.vals_a), ptr(self.keys_b), ptr(self.vals_b), ptr(self.ranges),
-                                   ptr(self.sort_ws), self.sort_ws_bytes, dmin, dmax, ptr(self.tile_order)))
+        if bs is None or R > self.capacity:
+            self._list_buffers(max(R, 1), dev)
+            bs = binsort_args()
+        bs.num_rendered, bs.depth_bits_min, bs.depth_bits_max = R, dmin, dmax
+        _lib.call("fdgs_raster_bin_sort", bs)
         plist = ptr(self.vals_b) if R > 0 else None
         _lib.call("fdgs_raster_blend_fwd",
                   _lib.BlendFwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.color),
