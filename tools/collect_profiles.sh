@@ -3,7 +3,7 @@
 #   gpurun_out/prof/stats   rocprofv3 --kernel-trace --stats of `bench.py` (default steps and warm-up, as the plain bench line)
 #   gpurun_out/prof/fetch, gpurun_out/prof/write, gpurun_out/prof/sq, gpurun_out/prof/mfma   one PMC pass each
 #                           (FETCH_SIZE, WRITE_SIZE, eight SQ counters: instruction counts and the split of the
-#                           waves' cycles, the matrix-core counters)
+#                           waves' cycles, the matrix-core counters, the LDS traffic counters)
 #   gpurun_out/bench.json   the plain bench line (with the CPU baseline)
 # Every GPU step has its own time limit and the chain stops at the first failure.
 set -e
@@ -22,6 +22,8 @@ timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_
 echo "sq pass done"
 timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE -d $OUT/prof/mfma -o mfma --output-format csv -- python3 $B > $OUT/prof/mfma.log 2>&1
 echo "mfma pass done"
+timeout -s KILL 300 rocprofv3 --pmc SQ_INSTS_LDS_LOAD_BANDWIDTH SQ_INSTS_LDS_STORE_BANDWIDTH SQ_INSTS_LDS_ATOMIC_BANDWIDTH SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE -d $OUT/prof/lds -o lds --output-format csv -- python3 $B > $OUT/prof/lds.log 2>&1
+echo "lds pass done"
 cd $ROOT
 F=$(find $OUT/prof/fetch -name '*counter_collection.csv' | head -1)
 W=$(find $OUT/prof/write -name '*counter_collection.csv' | head -1)
@@ -31,6 +33,8 @@ S=$(find $OUT/prof/sq -name '*counter_collection.csv' | head -1)
 python3 tools/sq_summary.py "$S" $OUT/kernel_stats.csv $OUT/pmc_sq.json > $OUT/pmc_sq.txt
 M=$(find $OUT/prof/mfma -name '*counter_collection.csv' | head -1)
 python3 tools/pmc_avg.py "$M" > $OUT/pmc_mfma.txt
+L=$(find $OUT/prof/lds -name '*counter_collection.csv' | head -1)
+python3 tools/lds_summary.py "$L" $OUT/kernel_stats.csv $OUT/pmc_lds.json > $OUT/pmc_lds.txt
 # keep the merged-back directory small: the raw per-dispatch CSVs are not needed afterwards
 find $OUT/prof -name '*counter_collection.csv' -delete
 find $OUT/prof -name '*kernel_trace.csv' -delete
