@@ -312,6 +312,47 @@ scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ 
     }
 }
 
+// scan_chunk_bases_kernel and scan_apply_kernel in one launch, for up to SCAN_FUSED_MAX_CHUNKS chunks: every
+// workgroup sums the chunk sums before its own (a few hundred words) instead of reading a base a launch of one
+// workgroup has prepared; the last workgroup also leaves the header (depth range, R).  The chunk sums stay as the
+// first launch wrote them.
+#define SCAN_FUSED_MAX_CHUNKS 4096
+__global__ void __launch_bounds__(SCAN_THREADS)
+scan_apply_fused_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ ws, uint32_t* __restrict__ out,
+                        int n, int n_chunks) {
+    __shared__ uint32_t lds4[4];
+    __shared__ uint32_t lds8[8];
+    const uint32_t* __restrict__ chunk_sums = ws + SCAN_HEADER;
+    uint32_t before = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) before += chunk_sums[j];
+    uint32_t chunk_base;
+    block_excl_scan_256(before, &chunk_base, lds4);          // only the total is used: the sum of the earlier chunks
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        s += v[k];
+    }
+    uint32_t total;
+    uint32_t run = chunk_base + block_excl_scan_256(s, &total, lds4);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        run += v[k];
+        if (base + k < n) out[base + k] = run;
+    }
+    if ((int)blockIdx.x == n_chunks - 1) {                   // uniform over the workgroup
+        uint32_t lo = 0xffffffffu, hi = 0u;
+        for (int j = threadIdx.x; j < n_chunks; j += SCAN_THREADS) {
+            lo = min(lo, chunk_sums[n_chunks + j]);
+            hi = max(hi, chunk_sums[2 * n_chunks + j]);
+        }
+        block_minmax_256(lo, hi, lds8);
+        if (threadIdx.x == 0) { ws[0] = lo; ws[1] = hi; ws[2] = chunk_base + total; ws[3] = 0u; }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Stage 3: duplicateWithKeys.  Gaussian i owns the list positions [offsets[i-1], offsets[i]) and gets one
 // (key, value) pair per touched tile there, tiles row-major.  key = (tile_id << 32) | bits(depth); when the
@@ -452,6 +493,12 @@ extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, voi
     hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
                        a->point_offsets, a->scan_workspace, n, chunks);
     FDGS_CHECK_LAUNCH();
+    if (chunks <= SCAN_FUSED_MAX_CHUNKS) {
+        hipLaunchKernelGGL(scan_apply_fused_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
+                           a->scan_workspace, a->point_offsets, n, chunks);
+        FDGS_CHECK_LAUNCH();
+        return FDGS_OK;
+    }
     hipLaunchKernelGGL(scan_chunk_bases_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, a->scan_workspace, chunks);
     FDGS_CHECK_LAUNCH();
     hipLaunchKernelGGL(scan_apply_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
