@@ -123,11 +123,13 @@ def reduce_densification_stats(radii, visibility, viewspace_grad, group=None):
     if not is_dist():
         return radii, visibility, viewspace_grad
     r = radii.contiguous()
-    g = viewspace_grad.contiguous()
     all_reduce_(r, dist.ReduceOp.MAX, group)
     if visibility is not None:          # None: the caller derives it as radii > 0, which commutes with the MAX
         v = visibility.to(torch.uint8).contiguous()
         all_reduce_(v, dist.ReduceOp.MAX, group)
         visibility = v.bool()
-    all_reduce_(g, dist.ReduceOp.SUM, group)
+    g = viewspace_grad
+    if g is not None:                   # None: the caller has summed it with the parameter gradients
+        g = g.contiguous()
+        all_reduce_(g, dist.ReduceOp.SUM, group)
     return r, visibility, g

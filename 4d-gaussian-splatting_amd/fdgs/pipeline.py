@@ -32,6 +32,7 @@ class ViewPipeline:
         self.N = self.W = self.H = -1
         self.capacity = 0
         self._one = None
+        self.deform_numel = 0                    # floats reserved in the gradient arena for the deformation field
 
     # ------------------------------------------------------------------------------------------------------
     def usable(self, stage):
@@ -39,6 +40,16 @@ class ViewPipeline:
         return (g.scaling_activation is torch.exp and g.opacity_activation is torch.sigmoid
                 and g.rotation_activation is torch.nn.functional.normalize
                 and ("coarse" in stage or self.net is not None))
+
+    def ensure(self, N, W, H, dev, deform_numel=None):
+        """Allocates (or re-allocates, when a size changed) the persistent buffers; run() does it by itself, a
+        caller that wants the gradient arena before the first run() calls it with the deformation field's size."""
+        if deform_numel is None:
+            deform_numel = self.deform_numel
+        if (N, W, H, deform_numel) != (self.N, self.W, self.H, self.deform_numel) or self._one is None \
+                or self._one.device != dev:
+            self.deform_numel = deform_numel
+            self._alloc(N, W, H, dev)
 
     def _alloc(self, N, W, H, dev):
         f32, i32 = torch.float32, torch.int32
@@ -75,12 +86,38 @@ class ViewPipeline:
         self.grad_image = e(3, H, W)
         # backward; two sets of per-Gaussian gradient buffers so that a second view can be added to the first
         self.dgeom = torch.zeros(N, _lib.GEOM_FLOATS, device=dev, dtype=f32)
-        self.sets = [dict(xyz=e(N, 3), means3D=e(N, 3), means2D=e(N, 3), scaling=e(N, 3), rotation=e(N, 4),
-                          opacity=e(N, 1), shs=e(N, 16, 3)) for _ in range(2)]
+        # Every gradient of a set that leaves this object lives in ONE flat array ("arena"), in the order
+        #   deformation field | means2D | xyz | scaling | rotation | opacity | shs        (each padded to 256 bytes)
+        # so that a data-parallel exchange is one in-place all-reduce of a contiguous range of it - all of it, all
+        # but the deformation field (coarse stage), or all but the SH block (exchanged earlier) - with no packing.
+        def pad(n):
+            return (n + 63) // 64 * 64
+        D = self.deform_numel
+        regions = (("dflat", (D,)), ("means2D", (N, 3)), ("xyz", (N, 3)), ("scaling", (N, 3)), ("rotation", (N, 4)),
+                   ("opacity", (N, 1)), ("shs", (N, 16, 3)))
+        self.sets, self.arenas, self.arena_marks = [], [], {}
+        for _ in range(2):
+            total = sum(pad(math.prod(shape)) for _, shape in regions)
+            arena = torch.zeros(total, device=dev, dtype=f32)
+            views, off = dict(means3D=e(N, 3)), 0
+            for name, shape in regions:
+                views[name] = arena[off:off + math.prod(shape)].view(shape)
+                self.arena_marks[name] = off
+                off += pad(math.prod(shape))
+            self.arena_marks["end"] = off
+            self.sets.append(views)
+            self.arenas.append(arena)
         self._one = torch.ones(1, device=dev, dtype=f32)
         self.r_host = torch.empty(3, dtype=i32).pin_memory()
         self._deform_ws = None
         self._R_last = 0
+
+    def exchange_range(self, fine, without_shs):
+        """The part of set 0's arena a data-parallel exchange has to sum over the ranks: a 1-D view."""
+        m = self.arena_marks
+        first = m["dflat"] if fine else m["means2D"]
+        last = m["shs"] if without_shs else m["end"]
+        return self.arenas[0][first:last]
 
     def _list_buffers(self, R, dev):
         if R <= self.capacity:
@@ -120,8 +157,7 @@ class ViewPipeline:
         dev = xyz.device
         N = xyz.shape[0]
         W, H = int(cam.image_width), int(cam.image_height)
-        if (N, W, H) != (self.N, self.W, self.H):
-            self._alloc(N, W, H, dev)
+        self.ensure(N, W, H, dev)
         fine = "fine" in stage
         S = self.sets[grad_set]
         sc, ro, op = g._scaling.detach(), g._rotation.detach(), g._opacity.detach()

@@ -100,20 +100,29 @@ class TrainStep:
         self._bind_parameters()
 
     # -- the per-view work, two routes to the same gradients ---------------------------------------------------
-    def _views_direct(self, views, scale, hook, while_waiting=None):
-        """fdgs/pipeline.py: the chain of C-ABI calls on persistent buffers; gradients attached to .grad here."""
-        if not views:
-            return None, None, None, None
+    def _views_direct(self, views, scale, hook, while_waiting=None, like=None):
+        """fdgs/pipeline.py: the chain of C-ABI calls on persistent buffers; gradients attached to .grad here.
+        Every gradient (and the view-space gradient) is a view of the pipeline's flat gradient arena.  `like`: a
+        camera of the global batch, for a rank that has no view of its own this step and only needs the arena (of
+        zeros) to take part in the exchange."""
         g = self.g
         fine = "fine" in self.stage
+        dev = g._xyz.device
+        n = g._xyz.shape[0]
+        cam0 = views[0] if views else like
         dgrads = None
+        deform_numel = None
         if fine:
             from . import deformation
             net = self.deforms.deformation_fields.deformation_net
             params = deformation._trainable(net)
             order, sizes, shapes = net._fdgs_grad_order, net._fdgs_grad_sizes, net._fdgs_grad_shapes
-            if self._dflat is None or self._dflat[0].device != g._xyz.device:
-                flat = torch.empty(sum(sizes), device=g._xyz.device, dtype=torch.float32)
+            deform_numel = sum(sizes)
+        self.pipeline.ensure(n, int(cam0.image_width), int(cam0.image_height), dev, deform_numel)
+        acc = self.pipeline.sets[0]
+        if fine:
+            flat = acc["dflat"]
+            if self._dflat is None or self._dflat[0].data_ptr() != flat.data_ptr():
                 dgrads = [None] * len(params)
                 for i, piece, shape in zip(order, flat.split_with_sizes(sizes), shapes):
                     dgrads[i] = piece.view(shape)
@@ -122,7 +131,10 @@ class TrainStep:
             for p, gr in zip(params, dgrads):     # attached now: the regulariser adds to them before the first
                 p.grad = gr                        # view's backward does; zeroed where the regulariser runs
         loss = psnr_sum = radii = None
-        acc = None
+        shs_grad = acc["shs"]
+        if not views:
+            self.pipeline.arenas[0].zero_()
+            radii = torch.zeros(n, dtype=torch.int32, device=dev)
         for i, cam in enumerate(views):
             vg = self.pipeline.run(cam, cam.original_image, scale, self.stage, grad_set=min(i, 1), deform_grads=dgrads,
                                    sh_hook=hook if fine else None, while_waiting=while_waiting if i == 0 else None)
@@ -130,16 +142,19 @@ class TrainStep:
             loss = vg.loss if loss is None else loss + vg.loss
             psnr_sum = vg.psnr if psnr_sum is None else psnr_sum + vg.psnr
             if i == 0:
-                acc = vg
+                shs_grad = vg.shs               # set 0's block, or the copy that is being exchanged early
                 radii = vg.radii if len(views) == 1 else vg.radii.clone()
             else:
-                torch._foreach_add_([acc.xyz, acc.scaling, acc.rotation, acc.opacity, acc.shs, acc.means2D],
+                torch._foreach_add_([acc["xyz"], acc["scaling"], acc["rotation"], acc["opacity"], shs_grad,
+                                     acc["means2D"]],
                                     [vg.xyz, vg.scaling, vg.rotation, vg.opacity, vg.shs, vg.means2D])
                 radii = torch.maximum(radii, vg.radii)
-        self.last_psnr = psnr_sum / len(views) if len(views) > 1 else psnr_sum
-        g._xyz.grad, g._scaling.grad, g._rotation.grad, g._opacity.grad = acc.xyz, acc.scaling, acc.rotation, acc.opacity
-        g._features_dc.grad, g._features_rest.grad = acc.shs[:, :1, :], acc.shs[:, 1:, :]
-        return loss, radii, None, acc.means2D      # visibility = radii > 0 where a caller needs it
+        if views:
+            self.last_psnr = psnr_sum / len(views) if len(views) > 1 else psnr_sum
+        g._xyz.grad, g._scaling.grad, g._rotation.grad, g._opacity.grad = (acc["xyz"], acc["scaling"], acc["rotation"],
+                                                                          acc["opacity"])
+        g._features_dc.grad, g._features_rest.grad = shs_grad[:, :1, :], shs_grad[:, 1:, :]
+        return loss, radii, None, acc["means2D"]      # visibility = radii > 0 where a caller needs it
 
     def _views_autograd(self, views, scale, hook):
         """render() + autograd: the reference's interface (any activation callables, SSIM term)."""
@@ -231,7 +246,8 @@ class TrainStep:
                     box["reg"] = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
                     return box["reg"]
                 return None
-            loss, radii, vis, vgrad = self._views_direct(views, scale, hook, regulariser if views else None)
+            loss, radii, vis, vgrad = self._views_direct(views, scale, hook, regulariser if views else None,
+                                                         like=global_views[0] if global_views else None)
             if "reg" in box:        # already inside `loss` (added on the device by the first view's loss kernel)
                 reg, reg_w = None, None
         else:
@@ -239,7 +255,8 @@ class TrainStep:
         if reg_w is not None:
             # same gradients as adding the term to the loss, written into the planes' .grad in one launch
             reg = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
-        if not views:   # a rank without views this step still takes part in the collectives, with zeros for exactly the
+        if not views and not direct:
+            # a rank without views this step still takes part in the collectives, with zeros for exactly the
             # tensors that get a gradient in this stage on the other ranks (the deformation field: fine stage only)
             radii = torch.zeros(n, dtype=torch.int32, device=dev)
             vis = torch.zeros(n, dtype=torch.bool, device=dev)
@@ -252,8 +269,15 @@ class TrainStep:
         if dp.is_dist():
             # `early` is the same on every rank: the hook is armed only for one view per rank, and it fires
             # once per fine-stage render
-            (self.bucket_without_sh if len(early) == 1 else self.bucket).allreduce_()
-            radii, _, vgrad = dp.reduce_densification_stats(radii, None, vgrad)
+            if direct:
+                # every gradient and the view-space gradient are views of one flat array: one in-place SUM of the
+                # range this stage uses (without the SH block when that has travelled already), nothing packed
+                dp.all_reduce_(self.pipeline.exchange_range("fine" in self.stage, len(early) == 1),
+                               torch.distributed.ReduceOp.SUM)
+                radii, _, _ = dp.reduce_densification_stats(radii, None, None)
+            else:
+                (self.bucket_without_sh if len(early) == 1 else self.bucket).allreduce_()
+                radii, _, vgrad = dp.reduce_densification_stats(radii, None, vgrad)
             vis = radii > 0
         # fdgs_trainer.py:181-182, gaussian_model.py:182-184 in one launch
         losses.add_densification_stats(radii, vgrad, self.xyz_gradient_accum, self.denom, self.max_radii2D)
