@@ -144,14 +144,19 @@ class ViewPipeline:
     # ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def run(self, cam, gt, scale, stage, grad_set=0, deform_grads=None, want_psnr=True, sh_hook=None,
-            while_waiting=None):
+            while_waiting=None, sh_total=None):
         """Forward, loss and backward of one view.  gt: [3,H,W] float32 on the device.  scale: the view's share of
         the batch loss (1 / views in the batch).  deform_grads: the 34 gradient tensors of the deformation field in
         the order of fdgs.deformation._trainable, accumulated into (fine stage).  Returns a ViewGrads whose tensors
         are this object's buffers of set `grad_set` (valid until that set is used again).  while_waiting: callable
         run after the tile-list length has been requested from the device and before the host waits for it - work
         enqueued there (anything that does not depend on this view) runs while that 4-byte read is in flight; it may
-        return a device scalar (float32) that is added to this view's loss value."""
+        return a device scalar (float32) that is added to this view's loss value.
+        sh_hook: callable(g_sh) -> handle with wait(), or None.  It is called (fine stage) as soon as this view's
+        gradient of the SH coefficients is final, before the deformation backward is enqueued, with a tensor it may
+        overwrite (a data-parallel caller starts an all-reduce on it); the returned ViewGrads' `shs` is that tensor.
+        Without sh_total the tensor is a copy of this view's block; with sh_total (the running sum of the rank's
+        earlier views, a block of another set) this view's block is added to sh_total and sh_total is handed over."""
         g = self.g
         xyz = g._xyz.detach()
         dev = xyz.device
@@ -241,7 +246,11 @@ class ViewPipeline:
         pending = None
         if fine:
             if sh_hook is not None:          # data parallel: the SH gradient is final here and can start travelling
-                g_sh = S["shs"].clone()      # the kernels below still read this rank's own cotangent
+                if sh_total is not None:     # the sum of the rank's earlier views (another set's block): this view's
+                    sh_total.add_(S["shs"])  # block joins it and the total travels; S["shs"] stays as it is
+                    g_sh = sh_total
+                else:
+                    g_sh = S["shs"].clone()  # the kernels below still read this rank's own cotangent
                 pending = sh_hook(g_sh)
             G = _deformation._fill_params(net, deform_grads)
             b = _lib.DeformBwdArgs(N, P, ptr(xyz), None, float(cam.time), None if split else ptr(self.hidden),

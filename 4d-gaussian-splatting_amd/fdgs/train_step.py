@@ -136,8 +136,13 @@ class TrainStep:
             self.pipeline.arenas[0].zero_()
             radii = torch.zeros(n, dtype=torch.int32, device=dev)
         for i, cam in enumerate(views):
+            # the SH gradient of the rank is complete after its LAST view's rasterizer backward: it is handed to the
+            # hook there (one view: a copy of the view's block; several: the running sum, this view's block added)
+            last = i == len(views) - 1
             vg = self.pipeline.run(cam, cam.original_image, scale, self.stage, grad_set=min(i, 1), deform_grads=dgrads,
-                                   sh_hook=hook if fine else None, while_waiting=while_waiting if i == 0 else None)
+                                   sh_hook=hook if (fine and last) else None,
+                                   while_waiting=while_waiting if i == 0 else None,
+                                   sh_total=acc["shs"] if (i > 0 and hook is not None) else None)
             # a view's scalars live in one of the pipeline's two buffers, valid until the view after the next
             loss = vg.loss if loss is None else loss + vg.loss
             psnr_sum = vg.psnr if psnr_sum is None else psnr_sum + vg.psnr
@@ -145,9 +150,12 @@ class TrainStep:
                 shs_grad = vg.shs               # set 0's block, or the copy that is being exchanged early
                 radii = vg.radii if len(views) == 1 else vg.radii.clone()
             else:
-                torch._foreach_add_([acc["xyz"], acc["scaling"], acc["rotation"], acc["opacity"], shs_grad,
-                                     acc["means2D"]],
-                                    [vg.xyz, vg.scaling, vg.rotation, vg.opacity, vg.shs, vg.means2D])
+                into = [acc["xyz"], acc["scaling"], acc["rotation"], acc["opacity"], acc["means2D"]]
+                what = [vg.xyz, vg.scaling, vg.rotation, vg.opacity, vg.means2D]
+                if vg.shs.data_ptr() != shs_grad.data_ptr():    # not already summed for the early exchange
+                    into.append(shs_grad)
+                    what.append(vg.shs)
+                torch._foreach_add_(into, what)
                 radii = torch.maximum(radii, vg.radii)
         if views:
             self.last_psnr = psnr_sum / len(views) if len(views) > 1 else psnr_sum
@@ -221,9 +229,10 @@ class TrainStep:
             reg_w = tuple(w * share for w in self.regulation)
         early = []
         hook = None
-        # one view on every rank (so all ranks take this branch together): the view's SH gradient is the
-        # rank's whole contribution and can be exchanged while the deformation backward runs
-        if views and dp.is_dist() and len(global_views) == dp.rank_world()[1] and self.early_exchange:
+        # the same number of views on every rank (so all ranks take this branch together): after a rank's last
+        # view's rasterizer backward its SH gradient is complete and is exchanged while that view's deformation
+        # backward runs
+        if views and dp.is_dist() and len(global_views) % dp.rank_world()[1] == 0 and self.early_exchange:
             def hook(g_sh):
                 try:
                     work = dp.all_reduce_async(g_sh)

@@ -47,7 +47,7 @@ def main(out_dir):
                                    for p in step.params]).cpu())
     step.optimizer.step = record
     for i in range(3):
-        step([cams[2 * i + v] for v in range(views_per_step)])
+        step([cams[(2 * i + v) % len(cams)] for v in range(views_per_step)])
     torch.cuda.synchronize()
     out = {f"grad{i}": t for i, t in enumerate(recorded)}
     out.update(accum=step.xyz_gradient_accum.cpu(), denom=step.denom.cpu(), maxr=step.max_radii2D.cpu(),

@@ -14,9 +14,12 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def test_two_ranks_match_one_rank(tmp_path):
+@pytest.mark.parametrize("views", [2, 4])
+def test_two_ranks_match_one_rank(tmp_path, views):
+    """views = 2: one view per rank (its SH gradient travels as a copy while the deformation backward runs);
+    views = 4: two per rank (the SH gradient travels after the rank's last view, summed in place)."""
     worker = os.path.join(HERE, "dp_gpu_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FDGS_TEST_VIEWS=str(views))
     two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", worker, str(tmp_path)]
     r = subprocess.run(two, env=env, capture_output=True, text=True, timeout=280)
@@ -35,14 +38,15 @@ def test_two_ranks_match_one_rank(tmp_path):
     assert float(one["denom"].sum()) > 0 and torch.equal(a0["denom"], one["denom"]) and torch.equal(a0["maxr"], one["maxr"])
 
 
-def test_rccl_exchange_step_with_one_rank(tmp_path):
+@pytest.mark.parametrize("views", [1, 2])
+def test_rccl_exchange_step_with_one_rank(tmp_path, views):
     """The collectives of the exchange step through RCCL (backend "nccl") on the real device, in a group of one
     rank (FDGS_DP_SINGLE_RANK=1; two ranks cannot share a GPU under RCCL): parameter broadcast, the early
-    asynchronous all-reduce of the SH gradient, the flat gradient bucket, the int32 MAX and float SUM of the
-    statistics.  Every reduction is then an identity, so gradients and statistics must equal the plain run's
+    asynchronous all-reduce of the SH gradient (of a copy with one view, of the running sum with two), the
+    in-place all-reduce of the gradient arena, the int32 MAX of the radii.  Every reduction is then an identity, so gradients and statistics must equal the plain run's
     (to rounding: the backward kernels accumulate with atomics, whose order differs from run to run)."""
     worker = os.path.join(HERE, "dp_gpu_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FDGS_TEST_VIEWS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FDGS_TEST_VIEWS=str(views))
     r = subprocess.run([sys.executable, worker, str(tmp_path)], env=dict(env, FDGS_TEST_TAG="_plain"),
                        capture_output=True, text=True, timeout=200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
