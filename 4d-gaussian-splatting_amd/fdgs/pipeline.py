@@ -21,7 +21,7 @@ from ._lib import lib, ptr
 
 class ViewGrads:
     """Gradients of one view: per-Gaussian tensors (raw-parameter space) and the deformation field's flat buffer."""
-    __slots__ = ("xyz", "scaling", "rotation", "opacity", "shs", "means2D", "radii", "loss", "psnr")
+    __slots__ = ("xyz", "scaling", "rotation", "opacity", "shs", "means2D", "radii", "loss", "psnr", "early_exchanged")
 
 
 class ViewPipeline:
@@ -87,14 +87,17 @@ class ViewPipeline:
         # backward; two sets of per-Gaussian gradient buffers so that a second view can be added to the first
         self.dgeom = torch.zeros(N, _lib.GEOM_FLOATS, device=dev, dtype=f32)
         # Every gradient of a set that leaves this object lives in ONE flat array ("arena"), in the order
-        #   deformation field | means2D | xyz | scaling | rotation | opacity | shs        (each padded to 256 bytes)
-        # so that a data-parallel exchange is one in-place all-reduce of a contiguous range of it - all of it, all
-        # but the deformation field (coarse stage), or all but the SH block (exchanged earlier) - with no packing.
+        #   deformation field | xyz | means2D | scaling | rotation | opacity | shs        (each padded to 256 bytes)
+        # so that a data-parallel exchange is an in-place all-reduce of a contiguous range of it, with no packing:
+        # all of it; all but the deformation field (coarse stage); or in two parts - "early": means2D .. shs, final
+        # once the rasterizer backward has run (these reach their parameters through the residual adds only), and
+        # "late": deformation field + xyz, which the deformation backward produces.
         def pad(n):
             return (n + 63) // 64 * 64
         D = self.deform_numel
-        regions = (("dflat", (D,)), ("means2D", (N, 3)), ("xyz", (N, 3)), ("scaling", (N, 3)), ("rotation", (N, 4)),
+        regions = (("dflat", (D,)), ("xyz", (N, 3)), ("means2D", (N, 3)), ("scaling", (N, 3)), ("rotation", (N, 4)),
                    ("opacity", (N, 1)), ("shs", (N, 16, 3)))
+        self.arena_regions = regions
         self.sets, self.arenas, self.arena_marks = [], [], {}
         for _ in range(2):
             total = sum(pad(math.prod(shape)) for _, shape in regions)
@@ -112,12 +115,21 @@ class ViewPipeline:
         self._deform_ws = None
         self._R_last = 0
 
-    def exchange_range(self, fine, without_shs):
-        """The part of set 0's arena a data-parallel exchange has to sum over the ranks: a 1-D view."""
+    def exchange_range(self, fine, early_done):
+        """The part of set 0's arena a data-parallel exchange still has to sum over the ranks: a 1-D view."""
         m = self.arena_marks
-        first = m["dflat"] if fine else m["means2D"]
-        last = m["shs"] if without_shs else m["end"]
+        first = m["dflat"] if fine else m["xyz"]
+        last = m["means2D"] if early_done else m["end"]
         return self.arenas[0][first:last]
+
+    def early_views(self, buf):
+        """The named gradients inside `buf`, a 1-D tensor laid out like an arena's early range (means2D .. shs)."""
+        m = self.arena_marks
+        out = {}
+        for name, shape in self.arena_regions[2:]:
+            off = m[name] - m["means2D"]
+            out[name] = buf[off:off + math.prod(shape)].view(shape)
+        return out
 
     def _list_buffers(self, R, dev):
         if R <= self.capacity:
@@ -143,8 +155,8 @@ class ViewPipeline:
 
     # ------------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def run(self, cam, gt, scale, stage, grad_set=0, deform_grads=None, want_psnr=True, sh_hook=None,
-            while_waiting=None, sh_total=None):
+    def run(self, cam, gt, scale, stage, grad_set=0, deform_grads=None, want_psnr=True, early_hook=None,
+            while_waiting=None):
         """Forward, loss and backward of one view.  gt: [3,H,W] float32 on the device.  scale: the view's share of
         the batch loss (1 / views in the batch).  deform_grads: the 34 gradient tensors of the deformation field in
         the order of fdgs.deformation._trainable, accumulated into (fine stage).  Returns a ViewGrads whose tensors
@@ -152,11 +164,14 @@ class ViewPipeline:
         run after the tile-list length has been requested from the device and before the host waits for it - work
         enqueued there (anything that does not depend on this view) runs while that 4-byte read is in flight; it may
         return a device scalar (float32) that is added to this view's loss value.
-        sh_hook: callable(g_sh) -> handle with wait(), or None.  It is called (fine stage) as soon as this view's
-        gradient of the SH coefficients is final, before the deformation backward is enqueued, with a tensor it may
-        overwrite (a data-parallel caller starts an all-reduce on it); the returned ViewGrads' `shs` is that tensor.
-        Without sh_total the tensor is a copy of this view's block; with sh_total (the running sum of the rank's
-        earlier views, a block of another set) this view's block is added to sh_total and sh_total is handed over."""
+        early_hook: callable(buf, radii) -> handle with wait(), or None.  Called (fine stage) as soon as the
+        gradients that do not pass through the deformation backward are final - view-space gradient, scaling,
+        rotation, opacity, SH: the arena's early range - and before that backward is enqueued, with a flat tensor
+        it may overwrite (a data-parallel caller starts an all-reduce on it) and this view's radii; the returned
+        ViewGrads' means2D / scaling / rotation / opacity / shs are then views of that tensor.  With grad_set 0 the
+        tensor is a copy of the range (the backward still reads the view's own blocks as cotangents); with grad_set
+        1 the view's range is added to set 0's - the running sum of the rank's earlier views - and that is handed
+        over."""
         g = self.g
         xyz = g._xyz.detach()
         dev = xyz.device
@@ -242,16 +257,19 @@ class ViewPipeline:
                                          ptr(d_m3), ptr(S["means2D"]), ptr(S["scaling"]), ptr(S["rotation"]),
                                          ptr(S["opacity"]), ptr(S["shs"]), None, None, acts, 1))
         out = ViewGrads()
-        g_sh = S["shs"]
+        early = S
         pending = None
         if fine:
-            if sh_hook is not None:          # data parallel: the SH gradient is final here and can start travelling
-                if sh_total is not None:     # the sum of the rank's earlier views (another set's block): this view's
-                    sh_total.add_(S["shs"])  # block joins it and the total travels; S["shs"] stays as it is
-                    g_sh = sh_total
+            if early_hook is not None:       # data parallel: these gradients are final here and can start travelling
+                m = self.arena_marks
+                own = self.arenas[grad_set][m["means2D"]:m["end"]]
+                if grad_set != 0:            # the running sum of the rank's earlier views: this view's range joins it
+                    buf = self.arenas[0][m["means2D"]:m["end"]]
+                    buf.add_(own)
                 else:
-                    g_sh = S["shs"].clone()  # the kernels below still read this rank's own cotangent
-                pending = sh_hook(g_sh)
+                    buf = own.clone()        # the kernels below still read this view's own blocks as cotangents
+                pending = early_hook(buf, self.radii)
+                early = self.early_views(buf)
             G = _deformation._fill_params(net, deform_grads)
             b = _lib.DeformBwdArgs(N, P, ptr(xyz), None, float(cam.time), None if split else ptr(self.hidden),
                                    ptr(self.act) if split else None, ptr(self.mask) if split else None,
@@ -261,7 +279,8 @@ class ViewPipeline:
             _lib.call("fdgs_deform_bwd", b)
             if pending is not None:
                 pending.wait()
-        out.xyz, out.scaling, out.rotation, out.opacity = S["xyz"], S["scaling"], S["rotation"], S["opacity"]
-        out.shs, out.means2D, out.radii = g_sh, S["means2D"], self.radii
+        out.xyz, out.scaling, out.rotation, out.opacity = S["xyz"], early["scaling"], early["rotation"], early["opacity"]
+        out.shs, out.means2D, out.radii = early["shs"], early["means2D"], self.radii
+        out.early_exchanged = early is not S
         out.loss, out.psnr = loss_buf, (psnr_buf if want_psnr else None)
         return out

@@ -100,7 +100,7 @@ class TrainStep:
         self._bind_parameters()
 
     # -- the per-view work, two routes to the same gradients ---------------------------------------------------
-    def _views_direct(self, views, scale, hook, while_waiting=None, like=None):
+    def _views_direct(self, views, scale, early_hook, while_waiting=None, like=None):
         """fdgs/pipeline.py: the chain of C-ABI calls on persistent buffers; gradients attached to .grad here.
         Every gradient (and the view-space gradient) is a view of the pipeline's flat gradient arena.  `like`: a
         camera of the global batch, for a rank that has no view of its own this step and only needs the arena (of
@@ -131,38 +131,43 @@ class TrainStep:
             for p, gr in zip(params, dgrads):     # attached now: the regulariser adds to them before the first
                 p.grad = gr                        # view's backward does; zeroed where the regulariser runs
         loss = psnr_sum = radii = None
-        shs_grad = acc["shs"]
+        final = acc          # where the rank's summed means2D / scaling / rotation / opacity / shs end up
+        m = self.pipeline.arena_marks
         if not views:
             self.pipeline.arenas[0].zero_()
             radii = torch.zeros(n, dtype=torch.int32, device=dev)
         for i, cam in enumerate(views):
-            # the SH gradient of the rank is complete after its LAST view's rasterizer backward: it is handed to the
-            # hook there (one view: a copy of the view's block; several: the running sum, this view's block added)
+            # The gradients that do not pass through the deformation backward are complete for the rank after its
+            # LAST view's rasterizer backward: they are handed to the hook there (one view: a copy of the view's
+            # range; several: the running sum in set 0, this view's range added), with the rank's radii so far.
             last = i == len(views) - 1
+            hook_now = None
+            if early_hook is not None and fine and last:
+                def hook_now(buf, view_radii, prev=radii):
+                    return early_hook(buf, view_radii if prev is None else torch.maximum(prev, view_radii))
             vg = self.pipeline.run(cam, cam.original_image, scale, self.stage, grad_set=min(i, 1), deform_grads=dgrads,
-                                   sh_hook=hook if (fine and last) else None,
-                                   while_waiting=while_waiting if i == 0 else None,
-                                   sh_total=acc["shs"] if (i > 0 and hook is not None) else None)
+                                   early_hook=hook_now, while_waiting=while_waiting if i == 0 else None)
             # a view's scalars live in one of the pipeline's two buffers, valid until the view after the next
             loss = vg.loss if loss is None else loss + vg.loss
             psnr_sum = vg.psnr if psnr_sum is None else psnr_sum + vg.psnr
             if i == 0:
-                shs_grad = vg.shs               # set 0's block, or the copy that is being exchanged early
                 radii = vg.radii if len(views) == 1 else vg.radii.clone()
+                if vg.early_exchanged:          # one view: its early range travels as a copy
+                    final = dict(means2D=vg.means2D, scaling=vg.scaling, rotation=vg.rotation, opacity=vg.opacity,
+                                 shs=vg.shs)
             else:
-                into = [acc["xyz"], acc["scaling"], acc["rotation"], acc["opacity"], acc["means2D"]]
-                what = [vg.xyz, vg.scaling, vg.rotation, vg.opacity, vg.means2D]
-                if vg.shs.data_ptr() != shs_grad.data_ptr():    # not already summed for the early exchange
-                    into.append(shs_grad)
-                    what.append(vg.shs)
-                torch._foreach_add_(into, what)
+                own = self.pipeline.arenas[1]
+                if vg.early_exchanged:          # the early range was added for the exchange already: xyz is left
+                    acc["xyz"].add_(vg.xyz)
+                else:                           # one add over xyz .. shs (the deformation field accumulates in place)
+                    self.pipeline.arenas[0][m["xyz"]:m["end"]].add_(own[m["xyz"]:m["end"]])
                 radii = torch.maximum(radii, vg.radii)
         if views:
             self.last_psnr = psnr_sum / len(views) if len(views) > 1 else psnr_sum
-        g._xyz.grad, g._scaling.grad, g._rotation.grad, g._opacity.grad = (acc["xyz"], acc["scaling"], acc["rotation"],
-                                                                          acc["opacity"])
-        g._features_dc.grad, g._features_rest.grad = shs_grad[:, :1, :], shs_grad[:, 1:, :]
-        return loss, radii, None, acc["means2D"]      # visibility = radii > 0 where a caller needs it
+        g._xyz.grad = acc["xyz"]
+        g._scaling.grad, g._rotation.grad, g._opacity.grad = final["scaling"], final["rotation"], final["opacity"]
+        g._features_dc.grad, g._features_rest.grad = final["shs"][:, :1, :], final["shs"][:, 1:, :]
+        return loss, radii, None, final["means2D"]      # visibility = radii > 0 where a caller needs it
 
     def _views_autograd(self, views, scale, hook):
         """render() + autograd: the reference's interface (any activation callables, SSIM term)."""
@@ -184,7 +189,8 @@ class TrainStep:
         if loss is None:
             return None, None, None, None
         from . import deformation
-        deformation.RESIDUAL_GRAD_HOOK = hook
+        # with several views autograd sums their gradients itself: nothing is final before the last backward ends
+        deformation.RESIDUAL_GRAD_HOOK = hook if len(views) == 1 else None
         try:
             loss.backward()
         finally:
@@ -227,19 +233,31 @@ class TrainStep:
         if self.regulation is not None:
             share = 1.0 / dp.rank_world()[1]
             reg_w = tuple(w * share for w in self.regulation)
-        early = []
-        hook = None
+        early = []          # what has been exchanged while the last deformation backward ran: ("sh", tensor) on the
+        hook = None         # autograd route; ("range", flat tensor, radii, pending MAX of the radii) on the direct one
+        early_hook = None
         # the same number of views on every rank (so all ranks take this branch together): after a rank's last
-        # view's rasterizer backward its SH gradient is complete and is exchanged while that view's deformation
-        # backward runs
+        # view's rasterizer backward everything but the deformation field's and the positions' gradients is complete
+        # and is exchanged while that view's deformation backward runs
         if views and dp.is_dist() and len(global_views) % dp.rank_world()[1] == 0 and self.early_exchange:
-            def hook(g_sh):
+            def hook(g_sh):             # autograd route (one view per rank): the SH gradient
                 try:
                     work = dp.all_reduce_async(g_sh)
                 except Exception:       # the collective could not be started (the same on every rank): the
                     self.early_exchange = False     # gradient then travels with the bucket, now and later
                     return None
-                early.append(g_sh)
+                early.append(("sh", g_sh))
+                return work
+
+            def early_hook(buf, rank_radii):
+                try:
+                    work = dp.all_reduce_async(buf)
+                    r = rank_radii.clone()
+                    work_r = dp.all_reduce_async(r, torch.distributed.ReduceOp.MAX)
+                except Exception:
+                    self.early_exchange = False
+                    return None
+                early.append(("range", buf, r, work_r))
                 return work
         direct = (self.use_pipeline and self.lambda_dssim == 0 and self.pipeline.usable(self.stage)
                   and all(getattr(c, "original_image", None) is not None for c in views))
@@ -255,7 +273,7 @@ class TrainStep:
                     box["reg"] = losses.add_regulation_grad_(self.deforms.deformation_fields, *reg_w)
                     return box["reg"]
                 return None
-            loss, radii, vis, vgrad = self._views_direct(views, scale, hook, regulariser if views else None,
+            loss, radii, vis, vgrad = self._views_direct(views, scale, early_hook, regulariser if views else None,
                                                          like=global_views[0] if global_views else None)
             if "reg" in box:        # already inside `loss` (added on the device by the first view's loss kernel)
                 reg, reg_w = None, None
@@ -276,14 +294,21 @@ class TrainStep:
                     if p.requires_grad and p.grad is None and ("fine" in self.stage or id(p) in gaussian_ids):
                         p.grad = torch.zeros_like(p)
         if dp.is_dist():
-            # `early` is the same on every rank: the hook is armed only for one view per rank, and it fires
-            # once per fine-stage render
+            # `early` is the same on every rank: the hooks are armed only when every rank has the same number of
+            # views, and fire once, in the last view's backward
             if direct:
                 # every gradient and the view-space gradient are views of one flat array: one in-place SUM of the
-                # range this stage uses (without the SH block when that has travelled already), nothing packed
-                dp.all_reduce_(self.pipeline.exchange_range("fine" in self.stage, len(early) == 1),
+                # range that has not travelled yet (deformation field + positions after an early exchange), nothing
+                # packed; the radii went with the early exchange or take a MAX of their own
+                went_early = len(early) == 1 and early[0][0] == "range"
+                dp.all_reduce_(self.pipeline.exchange_range("fine" in self.stage, went_early),
                                torch.distributed.ReduceOp.SUM)
-                radii, _, _ = dp.reduce_densification_stats(radii, None, None)
+                if went_early:
+                    if early[0][3] is not None:
+                        early[0][3].wait()
+                    radii = early[0][2]
+                else:
+                    radii, _, _ = dp.reduce_densification_stats(radii, None, None)
             else:
                 (self.bucket_without_sh if len(early) == 1 else self.bucket).allreduce_()
                 radii, _, vgrad = dp.reduce_densification_stats(radii, None, vgrad)

@@ -314,6 +314,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     grouped = world > 1 or os.environ.get("FDGS_DP_SINGLE_RANK") == "1"    # the latter: RCCL rehearsal on one GPU
+    # RCCL prints a version banner to file descriptor 1 when its first communicator comes up; the contract of this
+    # script is ONE line on stdout.  Everything written to descriptor 1 before the result line goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if grouped:
         if share_gpu:
             dist.init_process_group(backend="gloo")
@@ -525,7 +530,10 @@ def main():
         ]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, g, net, train_cams[0], bg)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if grouped:
         dist.barrier()
         dist.destroy_process_group()
