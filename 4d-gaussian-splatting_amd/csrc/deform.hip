@@ -1169,8 +1169,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     if (reuse) planes_cl = const_cast<float*>(a->planes_channel_last);
     int rc = make_plane_set(&a->p, planes_cl, &hk.ps, !reuse, s);
     if (rc != FDGS_OK) return rc;
-    if (hipMemsetAsync(grads_cl, 0, pf * sizeof(float), s) != hipSuccess) return FDGS_ELAUNCH;
-    {
+    {   // (grads_cl is cleared where it is first used: at the head of the HexPlane tail, on that tail's stream)
         size_t off = 0;
         for (int l = 0; l < 2; ++l)
             for (int ci = 0; ci < 6; ++ci) {
@@ -1258,7 +1257,9 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         // dW0 is 128 rows of 128 bytes: every workgroup would hit every one of them; private copies instead
         float* slab_w = ws_yfeat + (size_t)48 * ((size_t)n + 16);
         float* slab_b = slab_w + (size_t)DW0_SLABS * DW * 32;
-        if (hipMemsetAsync(slab_w, 0, (size_t)DW0_SLABS * (DW * 32 + DW) * sizeof(float), hs) != hipSuccess)
+        // fold_later: these copies lie right before the dW2 / db2 copies and were cleared with them
+        if (!fold_later &&
+            hipMemsetAsync(slab_w, 0, (size_t)DW0_SLABS * (DW * 32 + DW) * sizeof(float), hs) != hipSuccess)
             return FDGS_ELAUNCH;
         w1.d[0] = WGradSDesc{ws_dhid, DW, yfeat, slab_w, 32, 1, 32,
                              a->dp.b0 ? slab_b : nullptr, DW0_SLABS, DW * 32, DW, nullptr, 0, nullptr, nullptr};
@@ -1281,6 +1282,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     };
     // pass 1b + dW0 + plane-gradient layout change: everything downstream of dfeat; runs on stream hs
     auto hex_tail = [&](hipStream_t hs) -> int {
+        if (hipMemsetAsync(grads_cl, 0, pf * sizeof(float), hs) != hipSuccess) return FDGS_ELAUNCH;
         // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
         hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
         hk.ws_df = ws_df; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
@@ -1405,9 +1407,14 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     // private copies of the small dW2 / db2 accumulators (split mode), folded into the outputs after the loop
     float* w2_slabs = ws_yfeat + (size_t)48 * ((size_t)n + 16) + (size_t)DW0_SLABS * (DW * 32 + DW);
     float* op_q = w2_slabs + (size_t)W2_SLABS * W2_SLAB_FLOATS;      // Q [128][128], then T [128]
-    if (split && hipMemsetAsync(w2_slabs, 0, ((size_t)W2_SLABS * W2_SLAB_FLOATS + DW * DW + DW) * sizeof(float), s) !=
-                     hipSuccess)
-        return FDGS_ELAUNCH;
+    {   // one clear for the dW2 / db2 copies and the opacity head's Q / T and, when the dW0 product runs on this
+        // stream (yfeat given), its copies, which lie right before them
+        const bool with_dw0 = split && a->yfeat;
+        const size_t dw0_floats = (size_t)DW0_SLABS * (DW * 32 + DW);
+        float* first = with_dw0 ? w2_slabs - dw0_floats : w2_slabs;
+        const size_t floats = (size_t)W2_SLABS * W2_SLAB_FLOATS + DW * DW + DW + (with_dw0 ? dw0_floats : 0);
+        if (split && hipMemsetAsync(first, 0, floats * sizeof(float), s) != hipSuccess) return FDGS_ELAUNCH;
+    }
     for (int c0 = 0; c0 < n; c0 += chunk_pts) {
         const int cn = (n - c0) < chunk_pts ? (n - c0) : chunk_pts;
         DeformBwdK kc = k;
