@@ -209,7 +209,7 @@ __device__ __forceinline__ void level_features(const PlaneSet& ps, int h, const 
 #define FRAG_PERMROWS 4      // row i carries column perm(i) = 16*((i>>2)&1) + 4*(i>>3) + (i&3)
 
 struct FragDesc { const float* src; float* dst; int I; int K; int ld; int mode; };
-#define FRAG_MAX 16
+#define FRAG_MAX 24
 struct FragTable { FragDesc d[FRAG_MAX]; int n; };
 
 __host__ __device__ __forceinline__ int frag_floats(int I, int K) { return ((I + 31) / 32) * ((K + 7) / 8) * 256; }
@@ -599,9 +599,8 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
             t.d[t.n++] = SFragDesc{a->p.w2[h], pk, h_head_dim[h], DW, DW, 0};
             k.pw2[h] = pk; pk += sfrag_vec4(h_head_dim[h], DW);
         }
-        rc = launch_pack_split(t, s);
-        if (rc != FDGS_OK) return rc;
-        t.n = 0;
+        // the padded biases ride in the same launch: 11 + 11 descriptors
+        static_assert(FRAG_MAX >= 22, "weights and biases of the forward in one table");
         t.d[t.n++] = SFragDesc{a->p.b0, reinterpret_cast<u32x4*>(pb), DW, DW, 0, FRAG_BIAS};
         k.pb0 = pb; pb += DW;
         for (int h = 0; h < 5; ++h) {
