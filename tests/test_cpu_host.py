@@ -165,3 +165,50 @@ def test_schedules_match_reference_values():
     assert (o, d) == (0.005, 0.0002)
     o, d = schedule.fine_thresholds(5000, 10000, 0.01, 0.005, 0.0004, 0.0002)
     assert abs(o - 0.0075) < 1e-15 and abs(d - 0.0003) < 1e-15
+
+
+def test_ctypes_structures_match_the_header(tmp_path):
+    """Every argument structure of fdgs/_lib.py against the C header: a small C program (gcc, host only) prints
+    sizeof and the offset of every field of the structure's C counterpart; names, order, offsets and sizes must
+    agree, so a field added to one side only fails here and not as a corrupted pointer on the GPU."""
+    import ctypes
+    import shutil
+    import subprocess
+    from fdgs import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = {"PreprocessFwdArgs": "fdgs_preprocess_fwd_args", "BinSortArgs": "fdgs_binsort_args",
+             "BlendFwdArgs": "fdgs_blend_fwd_args", "BlendBwdArgs": "fdgs_blend_bwd_args",
+             "PreprocessBwdArgs": "fdgs_preprocess_bwd_args", "DeformParams": "fdgs_deform_params",
+             "DeformParamGrads": "fdgs_deform_param_grads", "DeformFwdArgs": "fdgs_deform_fwd_args",
+             "DeformBwdArgs": "fdgs_deform_bwd_args", "HexFeaturesArgs": "fdgs_hexplane_features_args",
+             "L1FwdArgs": "fdgs_l1_fwd_args", "L1BwdArgs": "fdgs_l1_bwd_args",
+             "DensifyStatsArgs": "fdgs_densify_stats_args", "PlaneRegArgs": "fdgs_plane_reg_args",
+             "AdamArgs": "fdgs_adam_args", "DensifyClassifyArgs": "fdgs_densify_classify_args",
+             "PruneClassifyArgs": "fdgs_prune_classify_args", "SurgeryPlanArgs": "fdgs_surgery_plan_args",
+             "SurgeryApplyArgs": "fdgs_surgery_apply_args", "SplitChildrenArgs": "fdgs_split_children_args",
+             "SsimFwdArgs": "fdgs_ssim_fwd_args", "SsimBwdArgs": "fdgs_ssim_bwd_args"}
+    declared = {name for name in dir(_lib) if isinstance(getattr(_lib, name), type)
+                and issubclass(getattr(_lib, name), ctypes.Structure) and getattr(_lib, name) is not ctypes.Structure}
+    assert declared == set(pairs), declared ^ set(pairs)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "fdgs.h"', 'int main(void) {']
+    for cls, cname in pairs.items():
+        lines.append(f'  printf("{cls} sizeof %zu\\n", sizeof({cname}));')
+        for field, _ in getattr(_lib, cls)._fields_:
+            # a trailing underscore only keeps a Python keyword out of the way (in_ is the C field `in`)
+            lines.append(f'  printf("{cls} {field} %zu\\n", offsetof({cname}, {field.rstrip("_")}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True,
+                   capture_output=True, text=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cls, field, value = line.split()
+        c = getattr(_lib, cls)
+        want = ctypes.sizeof(c) if field == "sizeof" else getattr(c, field).offset
+        assert int(value) == want, (cls, field, int(value), want)
+        seen += 1
+    assert seen == sum(1 + len(getattr(_lib, c)._fields_) for c in pairs)
