@@ -209,7 +209,7 @@ __device__ __forceinline__ void level_features(const PlaneSet& ps, int h, const 
 #define FRAG_PERMROWS 4      // row i carries column perm(i) = 16*((i>>2)&1) + 4*(i>>3) + (i&3)
 
 struct FragDesc { const float* src; float* dst; int I; int K; int ld; int mode; };
-#define FRAG_MAX 24
+#define FRAG_MAX 36
 struct FragTable { FragDesc d[FRAG_MAX]; int n; };
 
 __host__ __device__ __forceinline__ int frag_floats(int I, int K) { return ((I + 31) / 32) * ((K + 7) / 8) * 256; }
@@ -541,7 +541,12 @@ static int launch_pack(const FragTable& t, hipStream_t s) {
 
 // fills ps with the channel-last plane addresses inside ws and (unless the caller
 // says ws already holds them) rebuilds the copies with one launch
-static int make_plane_set(const fdgs_deform_params* p, float* ws, PlaneSet* ps, bool rebuild, hipStream_t s) {
+struct SFragTable;
+static void add_plane_copy(SFragTable* into, const float* src, float* dst, int texels);
+// With `into`, the copies are left as twelve entries of that table (the split path packs its weights with the
+// same launch) and nothing is launched here.
+static int make_plane_set(const fdgs_deform_params* p, float* ws, PlaneSet* ps, bool rebuild, hipStream_t s,
+                          SFragTable* into = nullptr) {
     PlaneTable t;
     size_t off = 0;
     int max_hw = 0;
@@ -553,21 +558,26 @@ static int make_plane_set(const fdgs_deform_params* p, float* ws, PlaneSet* ps, 
             t.dst[6 * l + ci] = ws + off;
             t.hw[6 * l + ci] = hw;
             ps->pl[l][ci] = ws + off;
+            if (rebuild && into) add_plane_copy(into, p->planes[l][ci], ws + off, hw);
             off += (size_t)hw * DF;
             if (hw > max_hw) max_hw = hw;
         }
     }
-    if (rebuild) {
+    if (rebuild && !into) {
         hipLaunchKernelGGL(planes_to_channel_last_kernel, dim3((max_hw + 255) / 256, 12), dim3(256), 0, s, t);
         FDGS_CHECK_LAUNCH();
     }
     return FDGS_OK;
 }
 
-static int launch_pack_split(const SFragTable& t, hipStream_t s) {
-    hipLaunchKernelGGL(pack_split_kernel, dim3(8, t.n), dim3(256), 0, s, t);
+static int launch_pack_split(const SFragTable& t, hipStream_t s, int blocks_per_entry = 8) {
+    hipLaunchKernelGGL(pack_split_kernel, dim3(blocks_per_entry, t.n), dim3(256), 0, s, t);
     FDGS_CHECK_LAUNCH();
     return FDGS_OK;
+}
+static void add_plane_copy(SFragTable* into, const float* src, float* dst, int texels) {
+    static_assert(DF == 16, "the plane entries of pack_split_kernel move 16 channels");
+    into->d[into->n++] = SFragDesc{src, reinterpret_cast<u32x4*>(dst), texels, 0, 0, FRAG_PLANE};
 }
 
 // split-mode forward workspace, in floats after the plane copies:
@@ -583,14 +593,14 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
     HexFeatSK g;
     k.n = g.n = a->num_points;
     float* ws = (float*)a->workspace;
-    int rc = make_plane_set(&a->p, ws, &g.ps, true, s);
+    SFragTable t;
+    t.n = 0;
+    int rc = make_plane_set(&a->p, ws, &g.ps, true, s, &t);    // twelve entries: the channel-last plane copies
     if (rc != FDGS_OK) return rc;
     u32x4* pk = reinterpret_cast<u32x4*>(ws + total_plane_floats(&a->p));
     float* pb = reinterpret_cast<float*>(pk) + fwd_packed_floats(FDGS_MATMUL_SPLIT_BF16);
     u32x4* feat = reinterpret_cast<u32x4*>(pb + fwd_split_bias_floats());
     {
-        SFragTable t;
-        t.n = 0;
         t.d[t.n++] = SFragDesc{a->p.w0, pk, DW, 32, 32, FRAG_FEATMAP};
         k.pw0 = pk; pk += sfrag_vec4(DW, 32);
         for (int h = 0; h < 5; ++h) {
@@ -599,8 +609,8 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
             t.d[t.n++] = SFragDesc{a->p.w2[h], pk, h_head_dim[h], DW, DW, 0};
             k.pw2[h] = pk; pk += sfrag_vec4(h_head_dim[h], DW);
         }
-        // the padded biases ride in the same launch: 11 + 11 descriptors
-        static_assert(FRAG_MAX >= 22, "weights and biases of the forward in one table");
+        // the padded biases ride in the same launch: 12 + 11 + 11 descriptors
+        static_assert(FRAG_MAX >= 34, "plane copies, weights and biases of the forward in one table");
         t.d[t.n++] = SFragDesc{a->p.b0, reinterpret_cast<u32x4*>(pb), DW, DW, 0, FRAG_BIAS};
         k.pb0 = pb; pb += DW;
         for (int h = 0; h < 5; ++h) {
@@ -609,7 +619,7 @@ static int deform_fwd_split(const fdgs_deform_fwd_args* a, hipStream_t s) {
             t.d[t.n++] = SFragDesc{a->p.b2[h], reinterpret_cast<u32x4*>(pb), h_head_dim[h], 64, 0, FRAG_BIAS};
             k.pb2[h] = pb; pb += 64;
         }
-        rc = launch_pack_split(t, s);
+        rc = launch_pack_split(t, s, 64);     // 64 workgroups per entry: the largest plane has tens of thousands of texels
         if (rc != FDGS_OK) return rc;
     }
     g.aabb = a->p.aabb; g.xyz = a->xyz; g.time = a->time; g.time_scalar = a->time_scalar;
@@ -1112,7 +1122,7 @@ static size_t bwd_ysplit_floats(int matmul, int n) {
 static size_t bwd_yfeat_floats(int matmul, int n) {
     return matmul == FDGS_MATMUL_SPLIT_BF16
                ? (size_t)48 * ((size_t)n + 16) + (size_t)DW0_SLABS * (DW * 32 + DW) + (size_t)W2_SLABS * W2_SLAB_FLOATS +
-                     (size_t)(DW * DW + DW)                  // Q and T of the one-output head (opacity_fold_kernel)
+                     (size_t)(DW * DW + DW)                  // Q and T of the one-output head (deform_bwd_finish_kernel)
                : 0;
 }
 // brick binning of the HexPlane backward, in 4-byte words: perm [n], brick_of [n] (16 bit, rounded up),
@@ -1542,8 +1552,6 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         OpacityFoldK of;
         of.Q = op_q; of.T = op_q + DW * DW; of.w1 = a->p.w1[3]; of.b1 = a->p.b1[3]; of.w2 = a->p.w2[3];
         of.dw1 = a->dp.w1[3]; of.db1 = a->dp.b1[3]; of.dw2 = a->dp.w2[3];
-        hipLaunchKernelGGL(opacity_fold_kernel, dim3(DW), dim3(DW), 0, s, of);
-        FDGS_CHECK_LAUNCH();
         static const int row0[5] = {0, 3, 6, 10, 11};
         SlabReduceK sr;
         for (int e = 0; e < SLAB_ENTRIES; ++e) { sr.slab[e] = nullptr; sr.out[e] = nullptr; sr.count[e] = 0; sr.stride[e] = 0; }
@@ -1557,7 +1565,11 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         if (dw0_slab_w) { sr.slab[10] = dw0_slab_w; sr.out[10] = a->dp.w0; sr.count[10] = DW * 32; sr.stride[10] = DW * 32; }
         if (dw0_slab_b) { sr.slab[11] = dw0_slab_b; sr.out[11] = a->dp.b0; sr.count[11] = DW; sr.stride[11] = DW; }
         sr.slabs = W2_SLABS;
-        hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(8, 12), dim3(256), 0, s, sr);
+        // the opacity head's dW2 comes from the fold (its rows of the copies are zero): it is written by one of the
+        // two halves of this launch only
+        sr.out[3] = nullptr;
+        static_assert(DW % 8 == 0 && DW % 64 == 0 && DW <= 256, "rows of the opacity fold over the launch's workgroups");
+        hipLaunchKernelGGL(deform_bwd_finish_kernel, dim3(8, SLAB_ENTRIES + DW / 8), dim3(256), 0, s, sr, of);
         FDGS_CHECK_LAUNCH();
     }
     if (side) {                                 // join

@@ -90,6 +90,7 @@ __device__ __forceinline__ floatx16 mma_split(const Split3& a, const Split3& b, 
 // lane (pieces h, m, l), lane (c, g) holding element(32 ib + c, kidx(j, g, e)).
 // ---------------------------------------------------------------------------
 #define FRAG_BIAS 8          // not a matrix: a bias vector, copied and zero-padded
+#define FRAG_PLANE 16        // not a matrix: a feature plane [16][I texels], rewritten channel-last [I][16]
 struct SFragDesc { const float* src; u32x4* dst; int I; int K; int ld; int mode; };
 struct SFragTable { SFragDesc d[FRAG_MAX]; int n; };
 
@@ -102,6 +103,18 @@ pack_split_kernel(SFragTable t) {
     for (int i = 1; i < FRAG_MAX; ++i)
         if ((int)blockIdx.y == i) d = t.d[i];
     if ((int)blockIdx.y >= t.n) return;
+    if (d.mode & FRAG_PLANE) {
+        float* dst = reinterpret_cast<float*>(d.dst);
+        for (int tx = blockIdx.x * blockDim.x + threadIdx.x; tx < d.I; tx += gridDim.x * blockDim.x) {
+            float v[16];
+#pragma unroll
+            for (int ch = 0; ch < 16; ++ch) v[ch] = d.src[(size_t)ch * d.I + tx];
+            float4* q = reinterpret_cast<float4*>(dst + (size_t)tx * 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) q[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        }
+        return;
+    }
     if (d.mode & FRAG_BIAS) {            // plain copy of I floats, zero-padded to K
         float* dst = reinterpret_cast<float*>(d.dst);
         for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < d.K; idx += gridDim.x * blockDim.x)
@@ -1129,7 +1142,7 @@ struct WGrad2SK {
     // line serialise in its L2 channel); wgrad_slab_reduce_kernel folds them into dw2.  NULL: straight into dw2
     float* dw2_slabs; int slabs;
     int small_heads;                             // NOB = 1 walks heads 0 .. small_heads - 1 (3: the opacity head's dW2
-                                                 // comes from opacity_fold_kernel instead)
+                                                 // comes from deform_bwd_finish_kernel instead)
 };
 
 // NOB = 2: the shs head alone (48 rows = two row blocks).  NOB = 1: the four small heads TOGETHER, their
@@ -1262,25 +1275,47 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
 // the dW1 product above) the kernel above yields Q[f][n] = sum_p X[p][f] relu(hidden)[p][n] and T[f] = sum_p X[p][f],
 // and, h1 being W1 relu(hidden) + b1 where the mask is set,
 //   dW1[f][n] = w2[f] Q[f][n],   db1[f] = w2[f] T[f],   dW2[f] = sum_n W1[f][n] Q[f][n] + b1[f] T[f].
-// One workgroup per row f.
+// One workgroup per row f (the second half of deform_bwd_finish_kernel).
 struct OpacityFoldK { const float* Q; const float* T; const float* w1; const float* b1; const float* w2;
                       float* dw1; float* db1; float* dw2; };
-__global__ void __launch_bounds__(DW)
-opacity_fold_kernel(OpacityFoldK a) {
+
+// wgrad_slab_reduce_kernel and the fold above in one launch (they end the backward and touch disjoint outputs,
+// provided the opacity head's dW2 is not among the slab destinations): workgroups (x, y < SLAB_ENTRIES) fold the
+// copies of entry y, workgroups (x, y >= SLAB_ENTRIES) take row f = 8 (y - SLAB_ENTRIES) + x of the opacity fold.
+__global__ void __launch_bounds__(256)
+deform_bwd_finish_kernel(SlabReduceK a, OpacityFoldK o) {
     __shared__ float part[2];
-    const int f = blockIdx.x, n = threadIdx.x;
-    const float q = a.Q[f * DW + n];
-    const float w2f = a.w2[f];
-    if (a.dw1) a.dw1[f * DW + n] += w2f * q;
-    float s = a.w1[f * DW + n] * q;
+    if ((int)blockIdx.y < SLAB_ENTRIES) {
+        const float* __restrict__ src = a.slab[0]; float* __restrict__ dst = a.out[0];
+        int count = a.count[0], stride = a.stride[0];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((n & 63) == 0) part[n >> 6] = s;
+        for (int e = 1; e < SLAB_ENTRIES; ++e)
+            if ((int)blockIdx.y == e) { src = a.slab[e]; dst = a.out[e]; count = a.count[e]; stride = a.stride[e]; }
+        if (!dst) return;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+            float s = 0.0f;
+            for (int k = 0; k < a.slabs; ++k) s += src[(size_t)k * stride + i];
+            dst[i] += s;
+        }
+        return;
+    }
+    const int f = 8 * ((int)blockIdx.y - SLAB_ENTRIES) + (int)blockIdx.x, n = threadIdx.x;
+    const bool live = f < DW && n < DW;                       // uniform per wave: DW is a multiple of 64
+    float s = 0.0f, w2f = 0.0f;
+    if (live) {
+        const float q = o.Q[f * DW + n];
+        w2f = o.w2[f];
+        if (o.dw1) o.dw1[f * DW + n] += w2f * q;
+        s = o.w1[f * DW + n] * q;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (live && (n & 63) == 0) part[n >> 6] = s;
     __syncthreads();
-    if (n == 0) {
-        const float t = a.T[f];
-        if (a.dw2) a.dw2[f] += part[0] + part[1] + a.b1[f] * t;
-        if (a.db1) a.db1[f] += w2f * t;
+    if (live && n == 0) {
+        const float t = o.T[f];
+        if (o.dw2) o.dw2[f] += part[0] + part[1] + o.b1[f] * t;
+        if (o.db1) o.db1[f] += w2f * t;
     }
 }
 

@@ -10,9 +10,63 @@
 
 #pragma clang fp contract(off)
 
+// Shared by stage 1 (which leaves per-workgroup sums) and the scan of stage 2.
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int d = 1; d < FDGS_WAVE; d <<= 1) {
+        uint32_t n = __shfl_up(v, d);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread (256 threads); returns the
+// exclusive prefix, *total gets the block total.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total, uint32_t* lds4) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == 63) lds4[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t s = lds4[w];
+        if (w < wave) base += s;
+    }
+    *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+// Scan workspace: [0] smallest and [1] largest depth bit pattern among the listed Gaussians (0xffffffff / 0 when
+// there are none), [2] R = the total, [3] unused, then per group of 256 Gaussians (one workgroup of stage 1):
+// sum -> exclusive base, depth minimum, depth maximum.
+#define SCAN_HEADER 4
+#define SCAN_GROUP 256
+#define SCAN_GROUPS_PER_CHUNK (SCAN_CHUNK / SCAN_GROUP)
+
+__device__ __forceinline__ void block_minmax_256(uint32_t& lo, uint32_t& hi, uint32_t* lds8) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { lds8[wave] = lo; lds8[4 + wave] = hi; }
+    __syncthreads();
+    lo = min(min(lds8[0], lds8[1]), min(lds8[2], lds8[3]));
+    hi = max(max(lds8[4], lds8[5]), max(lds8[6], lds8[7]));
+}
+
 // ---------------------------------------------------------------------------
 // Stage 1: one thread per Gaussian.  HBM-bound: reads 59 floats, writes the
-// 48-byte record + radius + tiles_touched.
+// 48-byte record + radius + tiles_touched.  Each workgroup also leaves the sum of its 256 tile counts and the
+// smallest / largest depth bit pattern among its listed Gaussians in the scan workspace: the first level of the scan.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
@@ -23,8 +77,9 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
         sh_tile_copy<true>(sh_tile, const_cast<float*>(a.shs) + (size_t)first * 48, rows);
         __syncthreads();
     }
-    if ((int)threadIdx.x >= rows) return;
-    const int i = first + threadIdx.x;
+    // threads past the last Gaussian stay for the workgroup's reductions: they recompute the first row and store nothing
+    const bool live = (int)threadIdx.x < rows;
+    const int i = live ? first + (int)threadIdx.x : first;
     const int W = a.image_width, H = a.image_height;
     const int gx = (W + FDGS_TILE - 1) / FDGS_TILE, gy = (H + FDGS_TILE - 1) / FDGS_TILE;
     const float* __restrict__ V = a.viewmatrix;
@@ -36,7 +91,7 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
     const float pvx = V[0] * x + V[4] * y + V[8] * z + V[12];
     const float pvy = V[1] * x + V[5] * y + V[9] * z + V[13];
     const float pvz = V[2] * x + V[6] * y + V[10] * z + V[14];
-    bool visible = pvz > FDGS_NEAR_Z;
+    bool visible = live && pvz > FDGS_NEAR_Z;
 
     int radius = 0;
     uint32_t touched = 0;
@@ -181,96 +236,36 @@ preprocess_fwd_kernel(fdgs_preprocess_fwd_args a) {
     }
     float op = visible ? a.opacities[i] : 0.0f;
     if (visible && (a.activations & FDGS_ACT_OPACITY_SIGMOID)) op = 1.0f / (1.0f + expf(-op));
-    grec[0] = make_float4(px, py, conA, conB);
-    grec[1] = make_float4(conC, op, cr, cg);
-    grec[2] = make_float4(cb, pvz, __int_as_float(fdgs_pack_radius(radius, clampmask)),
-                          __uint_as_float(visible ? fdgs_pack_reach(conA, conB, conC, op) : 0xfc00fc00u));
-    a.radii[i] = radius;
-    a.tiles_touched[i] = touched;
-    // until the scan writes it, point_offsets carries the depth bits of the Gaussians that enter the tile lists
-    // (0 otherwise: a listed depth is > 0.2): the scan kernels reduce them to the frame's depth range
-    a.point_offsets[i] = touched ? __float_as_uint(pvz) : 0u;
-}
-
-// ---------------------------------------------------------------------------
-// Stage 2: inclusive scan of uint32 counts.  Three small launches:
-// per-chunk sums, a single-block scan of the chunk sums, per-chunk scan + base.
-// ---------------------------------------------------------------------------
-#define SCAN_THREADS 256
-#define SCAN_ITEMS 8
-#define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
-
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < FDGS_WAVE; d <<= 1) {
-        uint32_t n = __shfl_up(v, d);
-        if (lane >= d) v += n;
+    if (live) {
+        grec[0] = make_float4(px, py, conA, conB);
+        grec[1] = make_float4(conC, op, cr, cg);
+        grec[2] = make_float4(cb, pvz, __int_as_float(fdgs_pack_radius(radius, clampmask)),
+                              __uint_as_float(visible ? fdgs_pack_reach(conA, conB, conC, op) : 0xfc00fc00u));
+        a.radii[i] = radius;
+        a.tiles_touched[i] = touched;
     }
-    return v;
-}
-
-// Block-wide exclusive scan of one value per thread (256 threads); returns the
-// exclusive prefix, *total gets the block total.
-__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total, uint32_t* lds4) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = wave_incl_scan_u32(v, lane);
-    if (lane == 63) lds4[wave] = incl;
+    // first level of the scan and of the frame's depth range (a listed depth is > 0.2, so its bits are not 0)
+    uint32_t* lds = reinterpret_cast<uint32_t*>(sh_tile);    // the SH rows have been consumed
     __syncthreads();
-    uint32_t base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        uint32_t s = lds4[w];
-        if (w < wave) base += s;
-    }
-    *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-    __syncthreads();
-    return base + incl - v;
-}
-
-// Scan workspace: [0] smallest and [1] largest depth bit pattern among the listed Gaussians (0xffffffff / 0 when
-// there are none), [2] R = the total, [3] unused, then per chunk: sum -> exclusive base, depth minimum, depth maximum.
-#define SCAN_HEADER 4
-
-__device__ __forceinline__ void block_minmax_256(uint32_t& lo, uint32_t& hi, uint32_t* lds8) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_xor((int)lo, d));
-        hi = max(hi, (uint32_t)__shfl_xor((int)hi, d));
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) { lds8[wave] = lo; lds8[4 + wave] = hi; }
-    __syncthreads();
-    lo = min(min(lds8[0], lds8[1]), min(lds8[2], lds8[3]));
-    hi = max(max(lds8[4], lds8[5]), max(lds8[6], lds8[7]));
-}
-
-__global__ void __launch_bounds__(SCAN_THREADS)
-scan_chunk_sums_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ depth_bits,
-                       uint32_t* __restrict__ ws, int n, int n_chunks) {
-    __shared__ uint32_t lds4[4];
-    __shared__ uint32_t lds8[8];
-    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0, lo = 0xffffffffu, hi = 0u;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) {
-            s += in[base + k];
-            const uint32_t d = depth_bits[base + k];
-            if (d != 0u) { lo = min(lo, d); hi = max(hi, d); }
-        }
     uint32_t total;
-    block_excl_scan_256(s, &total, lds4);
-    block_minmax_256(lo, hi, lds8);
+    block_excl_scan_256(touched, &total, lds);
+    uint32_t lo = touched ? __float_as_uint(pvz) : 0xffffffffu, hi = touched ? __float_as_uint(pvz) : 0u;
+    block_minmax_256(lo, hi, lds + 4);
     if (threadIdx.x == 0) {
-        ws[SCAN_HEADER + blockIdx.x] = total;
-        ws[SCAN_HEADER + n_chunks + blockIdx.x] = lo;
-        ws[SCAN_HEADER + 2 * n_chunks + blockIdx.x] = hi;
+        const int n_groups = gridDim.x;
+        a.scan_workspace[SCAN_HEADER + blockIdx.x] = total;
+        a.scan_workspace[SCAN_HEADER + n_groups + blockIdx.x] = lo;
+        a.scan_workspace[SCAN_HEADER + 2 * n_groups + blockIdx.x] = hi;
     }
 }
 
+// ---------------------------------------------------------------------------
+// Stage 2: inclusive scan of uint32 counts.  Stage 1 has left the sum of every group of 256 counts; one launch
+// (scan_apply_fused_kernel) finishes the scan, or two (a single-block scan of the group sums, then per-chunk scan +
+// base) when there are more groups than a workgroup should sum for itself.
+// ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(SCAN_THREADS)
-scan_chunk_bases_kernel(uint32_t* __restrict__ ws, int n_chunks) {
+scan_group_bases_kernel(uint32_t* __restrict__ ws, int n_chunks) {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t lds8[8];
     uint32_t* __restrict__ chunk_sums = ws + SCAN_HEADER;
@@ -304,7 +299,7 @@ scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ 
         s += v[k];
     }
     uint32_t total;
-    uint32_t run = chunk_bases[SCAN_HEADER + blockIdx.x] + block_excl_scan_256(s, &total, lds4);
+    uint32_t run = chunk_bases[SCAN_HEADER + blockIdx.x * SCAN_GROUPS_PER_CHUNK] + block_excl_scan_256(s, &total, lds4);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         run += v[k];
@@ -312,19 +307,21 @@ scan_apply_kernel(const uint32_t* __restrict__ in, const uint32_t* __restrict__ 
     }
 }
 
-// scan_chunk_bases_kernel and scan_apply_kernel in one launch, for up to SCAN_FUSED_MAX_CHUNKS chunks: every
-// workgroup sums the chunk sums before its own (a few hundred words) instead of reading a base a launch of one
-// workgroup has prepared; the last workgroup also leaves the header (depth range, R).  The chunk sums stay as the
-// first launch wrote them.
-#define SCAN_FUSED_MAX_CHUNKS 4096
+// scan_group_bases_kernel and scan_apply_kernel in one launch, for up to SCAN_FUSED_MAX_GROUPS groups: every
+// workgroup sums the group sums before its own chunk (a few hundred to a few thousand words) instead of reading a
+// base a launch of one workgroup has prepared; the last workgroup also leaves the header (depth range, R).  The
+// group sums stay as stage 1 wrote them.
+#define SCAN_FUSED_MAX_GROUPS 8192
 __global__ void __launch_bounds__(SCAN_THREADS)
 scan_apply_fused_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ ws, uint32_t* __restrict__ out,
-                        int n, int n_chunks) {
+                        int n, int n_groups) {
     __shared__ uint32_t lds4[4];
     __shared__ uint32_t lds8[8];
     const uint32_t* __restrict__ chunk_sums = ws + SCAN_HEADER;
+    const int n_chunks = n_groups;                           // the three arrays are n_groups long
+    const int groups_before = min((int)blockIdx.x * SCAN_GROUPS_PER_CHUNK, n_groups);
     uint32_t before = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) before += chunk_sums[j];
+    for (int j = threadIdx.x; j < groups_before; j += SCAN_THREADS) before += chunk_sums[j];
     uint32_t chunk_base;
     block_excl_scan_256(before, &chunk_base, lds4);          // only the total is used: the sum of the earlier chunks
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
@@ -342,7 +339,7 @@ scan_apply_fused_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ 
         run += v[k];
         if (base + k < n) out[base + k] = run;
     }
-    if ((int)blockIdx.x == n_chunks - 1) {                   // uniform over the workgroup
+    if (blockIdx.x == gridDim.x - 1) {                       // uniform over the workgroup
         uint32_t lo = 0xffffffffu, hi = 0u;
         for (int j = threadIdx.x; j < n_chunks; j += SCAN_THREADS) {
             lo = min(lo, chunk_sums[n_chunks + j]);
@@ -366,10 +363,12 @@ scan_apply_fused_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ 
 __global__ void __launch_bounds__(256)
 duplicate_with_keys_kernel(int n, const float* __restrict__ geom, const uint32_t* __restrict__ offsets,
                            uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int gx, int gy,
-                           int depth_bits, uint32_t depth_min) {
+                           int depth_bits, uint32_t depth_min, uint32_t* __restrict__ ranges) {
     __shared__ uint32_t s_end[4][64], s_start[4][64], s_x0w[4][64], s_y0[4][64], s_depth[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // the tile ranges start as (0, 0) = empty; identifyTileRanges, five sort passes later, fills the others
+    for (int w = i; w < 2 * gx * gy; w += gridDim.x * 256) ranges[w] = 0u;
     const int ic = i < n ? i : n - 1;
     const uint32_t end = offsets[ic];
     const uint32_t start = i < n ? (i == 0 ? 0u : offsets[i - 1]) : end;
@@ -472,8 +471,8 @@ tile_order_kernel(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ or
 // ---------------------------------------------------------------------------
 extern "C" size_t fdgs_raster_scan_workspace_bytes(int32_t num_points) {
     if (num_points < 0) return 0;
-    size_t chunks = ((size_t)num_points + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    return (SCAN_HEADER + 3 * chunks + 1) * sizeof(uint32_t);
+    size_t groups = ((size_t)num_points + SCAN_GROUP - 1) / SCAN_GROUP;
+    return (SCAN_HEADER + 3 * groups + 1) * sizeof(uint32_t);
 }
 
 extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, void* stream) {
@@ -487,19 +486,17 @@ extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, voi
     if (!a->colors_precomp && !a->shs) return FDGS_EINVAL;
     if (!a->cov3D_precomp && (!a->scales || !a->rotations)) return FDGS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *a);
+    const int groups = (n + SCAN_GROUP - 1) / SCAN_GROUP;    // = workgroups of stage 1 = entries of the workspace arrays
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(groups), dim3(SCAN_GROUP), 0, s, *a);
     FDGS_CHECK_LAUNCH();
     const int chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
-                       a->point_offsets, a->scan_workspace, n, chunks);
-    FDGS_CHECK_LAUNCH();
-    if (chunks <= SCAN_FUSED_MAX_CHUNKS) {
+    if (groups <= SCAN_FUSED_MAX_GROUPS) {
         hipLaunchKernelGGL(scan_apply_fused_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
-                           a->scan_workspace, a->point_offsets, n, chunks);
+                           a->scan_workspace, a->point_offsets, n, groups);
         FDGS_CHECK_LAUNCH();
         return FDGS_OK;
     }
-    hipLaunchKernelGGL(scan_chunk_bases_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, a->scan_workspace, chunks);
+    hipLaunchKernelGGL(scan_group_bases_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, a->scan_workspace, groups);
     FDGS_CHECK_LAUNCH();
     hipLaunchKernelGGL(scan_apply_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
                        a->scan_workspace, a->point_offsets, n);
@@ -521,9 +518,9 @@ extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
     const int gx = fdgs_tiles_x(a->image_width), gy = fdgs_tiles_y(a->image_height);
     const int tiles = gx * gy;
     if (!a->ranges) return FDGS_EINVAL;
-    if (hipMemsetAsync(a->ranges, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s) != hipSuccess) return FDGS_ELAUNCH;
     const int64_t R = a->num_rendered;
     if (R == 0 || a->num_points == 0) {
+        if (hipMemsetAsync(a->ranges, 0, sizeof(uint32_t) * 2 * (size_t)tiles, s) != hipSuccess) return FDGS_ELAUNCH;
         if (a->tile_order) {
             hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, a->ranges, a->tile_order, tiles);
             FDGS_CHECK_LAUNCH();
@@ -556,7 +553,7 @@ extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
     uint64_t* kb = odd ? a->keys_sorted : a->keys_unsorted;
     uint32_t* vb = odd ? a->vals_sorted : a->vals_unsorted;
     hipLaunchKernelGGL(duplicate_with_keys_kernel, dim3((a->num_points + 255) / 256), dim3(256), 0, s, a->num_points,
-                       a->geom, a->point_offsets, ka, va, gx, gy, depth_bits, depth_min);
+                       a->geom, a->point_offsets, ka, va, gx, gy, depth_bits, depth_min, a->ranges);
     FDGS_CHECK_LAUNCH();
     int rc = fdgs_radix_sort_pingpong(ka, va, kb, vb, R, end_bit, a->sort_workspace, a->sort_workspace_bytes, s,
                                       depth_bits < 32 || depth_min != 0 ? depth_bits : 0, depth_min);
