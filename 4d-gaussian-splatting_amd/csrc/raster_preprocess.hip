@@ -7,6 +7,7 @@
 // that the integer stages are reproducible bit for bit by any IEEE
 // implementation that evaluates the same sequence.
 #include "fdgs_common.h"
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -490,7 +491,10 @@ extern "C" int fdgs_raster_preprocess_fwd(const fdgs_preprocess_fwd_args* a, voi
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(groups), dim3(SCAN_GROUP), 0, s, *a);
     FDGS_CHECK_LAUNCH();
     const int chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    if (groups <= SCAN_FUSED_MAX_GROUPS) {
+    // FDGS_SCAN_FUSED_MAX_GROUPS: the largest group count scanned by one launch (tests force the two-launch path)
+    const char* fused_env = getenv("FDGS_SCAN_FUSED_MAX_GROUPS");
+    const int fused_max = fused_env ? atoi(fused_env) : SCAN_FUSED_MAX_GROUPS;
+    if (groups <= fused_max) {
         hipLaunchKernelGGL(scan_apply_fused_kernel, dim3(chunks), dim3(SCAN_THREADS), 0, s, a->tiles_touched,
                            a->scan_workspace, a->point_offsets, n, groups);
         FDGS_CHECK_LAUNCH();

@@ -12,6 +12,10 @@ CASES = {
     "ragged": (1500, 70, 45, 8.0, 2, (0.0, 0.3, 0.7)),     # partial edge tiles, big splats, early termination
     "deg0": (800, 64, 64, 3.0, 0, (0.0, 0.0, 0.0)),
     "medium": (20000, 256, 256, 2.0, 3, (1.0, 1.0, 1.0)),
+    # Gaussian counts on the edges of the preprocess workgroup (256) and of the scan chunk (2048)
+    "n256": (256, 48, 32, 5.0, 1, (0.2, 0.2, 0.2)),
+    "n2049": (2049, 96, 80, 4.0, 3, (1.0, 1.0, 1.0)),
+    "n4096": (4096, 112, 64, 3.0, 2, (0.0, 0.0, 0.0)),
 }
 
 

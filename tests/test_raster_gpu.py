@@ -26,7 +26,7 @@ def _run_oracle(c, with_grad):
     return ins, m2, color, radii, depth, aux
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "deg0", "medium"])
+@pytest.mark.parametrize("name", ["small", "ragged", "deg0", "medium", "n256", "n2049", "n4096"])
 def test_forward_stages(name):
     from fdgs import rasterizer as fr
     c = rc.make_case(name)
@@ -68,7 +68,27 @@ def test_forward_stages(name):
     assert float((st.depth.cpu() - depth).abs().max()) <= dtol
 
 
-@pytest.mark.parametrize("name", ["small", "ragged", "deg0", "medium"])
+def test_scan_in_two_launches_gives_the_same_lists(monkeypatch):
+    """Beyond 8192 groups of 256 Gaussians the scan of the tile counts takes a second launch (a one-workgroup scan of
+    the group sums); forced here at a size the oracle handles."""
+    from fdgs import rasterizer as fr
+    c = rc.make_case("medium")
+    _, _, _, radii, _, aux = _run_oracle(c, False)
+    dev = torch.device("cuda:0")
+    S = _to_dev(c["S"], dev)
+    monkeypatch.setenv("FDGS_SCAN_FUSED_MAX_GROUPS", "0")
+    st = fr.rasterize_forward(c["means3D"].to(dev), c["shs"].to(dev), c["opacities"].reshape(-1).to(dev).contiguous(),
+                              c["scales"].to(dev), c["rotations"].to(dev), S, keep_keys=True)
+    torch.cuda.synchronize()
+    R = aux["keys"].numel()
+    assert st.num_rendered == R
+    assert torch.equal(st.point_offsets.cpu(), aux["offsets"])
+    assert torch.equal(st.keys_sorted[:R].cpu(), aux["sorted_keys"])
+    assert torch.equal(st.vals_sorted[:R].cpu(), aux["sorted_vals"])
+    assert torch.equal(st.ranges.cpu(), aux["ranges"])
+
+
+@pytest.mark.parametrize("name", ["small", "ragged", "deg0", "medium", "n2049"])
 def test_backward(name):
     from fdgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
     c = rc.make_case(name)
