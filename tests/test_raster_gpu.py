@@ -186,7 +186,7 @@ def test_precomputed_color_and_covariance(name):
     (img * gout.to(dev)).sum().backward()
     torch.cuda.synchronize()
     assert torch.equal(rad.cpu(), radii)
-    assert float((img.cpu() - color).abs().max()) <= IMG_TOL
+    assert float((img.detach().cpu() - color.detach()).abs().max()) <= IMG_TOL
     dtol = IMG_TOL * max(1.0, float(depth.abs().max()))
     assert float((dep.cpu() - depth).abs().max()) <= dtol
     for k, got, ref in [("means2D", m2d.grad, m2.grad)] + [(k, d[k].grad, ins[k].grad) for k in d]:
