@@ -9,6 +9,7 @@ iteration: a single flat-bucket SUM all-reduce of every parameter gradient
 densification statistics the trainer keeps (fdgs_trainer.py:125-126,146-148):
 radii MAX, visibility MAX (= OR), summed view-space gradient SUM.
 """
+import contextlib
 import os
 
 import torch
@@ -19,12 +20,29 @@ import torch.distributed as dist
 _SINGLE_RANK = os.environ.get("FDGS_DP_SINGLE_RANK") == "1"
 
 
+_LOCAL_ONLY = False
+
+
+@contextlib.contextmanager
+def local_only():
+    """Inside the block this rank behaves as a group of its own: every view of a batch stays here and no exchange
+    step is taken.  For timing the same batch on ONE GPU from inside an N-rank job (the other ranks must not step
+    meanwhile: the replicas differ afterwards)."""
+    global _LOCAL_ONLY
+    before, _LOCAL_ONLY = _LOCAL_ONLY, True
+    try:
+        yield
+    finally:
+        _LOCAL_ONLY = before
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _SINGLE_RANK)
+    return (not _LOCAL_ONLY and dist.is_available() and dist.is_initialized()
+            and (dist.get_world_size() > 1 or _SINGLE_RANK))
 
 
 def rank_world():
-    if dist.is_available() and dist.is_initialized():
+    if not _LOCAL_ONLY and dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
 

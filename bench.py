@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--batch8-steps", type=int, default=6,
                     help="at --gpus 1: steps of the extra leg with 8 views per iteration, the one-GPU point of the "
                          "fixed-global-batch scaling curve (0 = skip)")
+    ap.add_argument("--one-gpu-steps", type=int, default=5,
+                    help="at --gpus > 1: steps of the last leg, the same global batch on rank 0 alone while the other "
+                         "ranks wait (the one-GPU point of the scaling curve, measured inside the job; 0 = skip)")
     ap.add_argument("--cpu-tile-stride", type=int, default=48,
                     help="cpu baseline blends every k-th tile, and every (k/2)-th for a second estimate")
     ap.add_argument("--dry-run", action="store_true",
@@ -435,6 +438,27 @@ def main():
             fps_d2h = args.render_frames / max_over_ranks(time.perf_counter() - t1)
             del images
 
+    # last leg of an N-rank run: the SAME batch of B views on rank 0 alone (no exchange step), the one-GPU point of
+    # the strong-scaling curve measured inside this job.  The other ranks wait; the replicas differ afterwards,
+    # so nothing that steps follows.
+    one_gpu = one_gpu_error = None
+    if world > 1 and args.one_gpu_steps > 0:
+        sync()
+        if rank == 0:
+            try:
+                with dp.local_only():
+                    for i in range(2):
+                        step(batch(i))
+                    torch.cuda.synchronize()
+                    t4 = time.perf_counter()
+                    for i in range(args.one_gpu_steps):
+                        step(batch(2 + i))
+                    torch.cuda.synchronize()
+                    one_gpu = args.one_gpu_steps / (time.perf_counter() - t4)
+            except Exception as exc:       # a reference figure only: the measured line must still come out
+                one_gpu_error = repr(exc)
+        sync()
+
     if rank == 0:
         def avg_ms(name):
             ev = prof.get(name, [])
@@ -489,6 +513,9 @@ def main():
             "views_per_s": B * args.steps / elapsed,
             "train_it_s_fp32_mfma": fp32_mfma,
             "train_it_s_global_batch_8": batch8,
+            # N-rank runs: the same global batch timed on rank 0 alone at the end of this job, and value over it
+            "train_it_s_same_batch_one_gpu": one_gpu,
+            "speedup_over_one_gpu": (args.steps / elapsed / one_gpu) if one_gpu else None,
             "render_fps": fps,
             "render_fps_with_d2h": fps_d2h,
             "kernel_ms": per_call,
@@ -510,6 +537,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": dur * 1e3},
             "roofline_valu": valu_roofline,
         }
+        if one_gpu_error:
+            out["train_it_s_same_batch_one_gpu_error"] = one_gpu_error
         if share_gpu:
             out["rehearsal"] = "all ranks on one GPU over gloo: not a measurement"
         # the HBM-bound stages beside the north-star kernel: algorithmic bytes per call over the call's time

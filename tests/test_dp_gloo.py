@@ -63,6 +63,11 @@ def _worker(rank, world, port, out):
     vis = torch.stack([s[1] for s in stats]).any(0)
     vgrad = sum(s[2] for s in stats)
     radii, vis, vgrad = dp.reduce_densification_stats(radii, vis, vgrad)
+    # inside local_only() a rank of the group is a group of its own: it keeps every view and exchanges nothing
+    with dp.local_only():
+        assert not dp.is_dist() and dp.rank_world() == (0, 1)
+        assert len(dp.shard_views(views)) == len(views) and dp.local_loss_scale(len(views), len(views)) == 1.0 / len(views)
+    assert dp.is_dist() and dp.rank_world() == (rank, world)
     if rank == 0:
         torch.save({"grads": [p.grad for p in params], "radii": radii, "vis": vis, "vgrad": vgrad}, out)
     dist.barrier()
