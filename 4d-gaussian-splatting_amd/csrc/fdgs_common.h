@@ -35,6 +35,14 @@
 #define SH_C3_5 1.445305721320277f
 #define SH_C3_6 -0.5900435899266435f
 
+// Sort workspace: the radix sort's histogram area, then the area of the tile-binned sort (tile_sort.h): totals,
+// first positions, order and (tile, first, length) records of up to FDGS_TILE_SORT_MAX_TILES tiles, and the
+// table[workgroups][tiles] of counts.
+#define FDGS_RADIX_WS_WORDS (256u * 1024u + 256u)
+#define FDGS_TILE_SORT_MAX_TILES 32768
+#define FDGS_TILE_SORT_TABLE_WORDS (2u << 20)
+#define FDGS_TILE_SORT_WS_WORDS (7u * FDGS_TILE_SORT_MAX_TILES + FDGS_TILE_SORT_TABLE_WORDS + 64u)
+
 static inline int fdgs_tiles_x(int w) { return (w + FDGS_TILE - 1) / FDGS_TILE; }
 static inline int fdgs_tiles_y(int h) { return (h + FDGS_TILE - 1) / FDGS_TILE; }
 

@@ -43,7 +43,8 @@ static rs_plan rs_make_plan(int64_t n) {
 
 extern "C" size_t fdgs_raster_sort_workspace_bytes(int64_t num_rendered) {
     (void)num_rendered;
-    return ((size_t)RS_BINS * RS_MAX_BLOCKS + RS_BINS) * sizeof(uint32_t);
+    static_assert(FDGS_RADIX_WS_WORDS == RS_BINS * RS_MAX_BLOCKS + RS_BINS, "radix area of the sort workspace");
+    return ((size_t)FDGS_RADIX_WS_WORDS + FDGS_TILE_SORT_WS_WORDS) * sizeof(uint32_t);
 }
 
 __global__ void __launch_bounds__(RS_THREADS)

@@ -441,16 +441,22 @@ __device__ __forceinline__ int tile_length_class(uint32_t len) {      // larger 
     return ORDER_CLASSES - 1 - k;
 }
 
-__global__ void __launch_bounds__(1024)
-tile_order_kernel(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, int tiles) {
-    __shared__ uint32_t count[ORDER_CLASSES];
-    __shared__ uint32_t wsum[16];
-    for (int k = threadIdx.x; k < ORDER_CLASSES; k += 1024) count[k] = 0;
+// One workgroup of THREADS >= ORDER_CLASSES threads; the lengths come from `totals` [tiles] or, when that is null,
+// from the ranges.  count: ORDER_CLASSES words of LDS, wsum: THREADS / 64 words.
+template <int THREADS>
+__device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ totals,
+                                                 uint32_t* __restrict__ order, int tiles, uint32_t* count,
+                                                 uint32_t* wsum, const uint32_t* starts = nullptr,
+                                                 uint4* __restrict__ desc = nullptr) {
+    static_assert(THREADS >= ORDER_CLASSES, "one thread per length class in the scan");
+    for (int k = threadIdx.x; k < ORDER_CLASSES; k += THREADS) count[k] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < tiles; t += 1024)
-        atomicAdd(&count[tile_length_class(ranges[2 * t + 1] - ranges[2 * t])], 1u);
+    for (int t = threadIdx.x; t < tiles; t += THREADS) {
+        const uint32_t len = totals ? totals[t] : ranges[2 * t + 1] - ranges[2 * t];
+        atomicAdd(&count[tile_length_class(len)], 1u);
+    }
     __syncthreads();
-    // exclusive scan of the 512 class counts by the first 512 threads (8 waves)
+    // exclusive scan of the class counts by the first ORDER_CLASSES threads (8 waves)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t v = threadIdx.x < ORDER_CLASSES ? count[threadIdx.x] : 0u;
     uint32_t incl = wave_incl_scan_u32(v, lane);
@@ -461,11 +467,22 @@ tile_order_kernel(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ or
     __syncthreads();
     if (threadIdx.x < ORDER_CLASSES) count[threadIdx.x] = base + incl - v;   // first slot of the class
     __syncthreads();
-    for (int t = threadIdx.x; t < tiles; t += 1024) {
-        const uint32_t pos = atomicAdd(&count[tile_length_class(ranges[2 * t + 1] - ranges[2 * t])], 1u);
+    for (int t = threadIdx.x; t < tiles; t += THREADS) {
+        const uint32_t len = totals ? totals[t] : ranges[2 * t + 1] - ranges[2 * t];
+        const uint32_t pos = atomicAdd(&count[tile_length_class(len)], 1u);
         order[pos] = (uint32_t)t;
+        if (desc) desc[pos] = make_uint4((uint32_t)t, starts[t], len, 0u);     // starts: first list positions (LDS)
     }
 }
+
+__global__ void __launch_bounds__(1024)
+tile_order_kernel(const uint32_t* __restrict__ ranges, uint32_t* __restrict__ order, int tiles) {
+    __shared__ uint32_t count[ORDER_CLASSES];
+    __shared__ uint32_t wsum[16];
+    tile_order_block<1024>(ranges, nullptr, order, tiles, count, wsum);
+}
+
+#include "tile_sort.h"
 
 // ---------------------------------------------------------------------------
 // Host entry points
@@ -535,6 +552,14 @@ extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
         !a->vals_sorted || !a->sort_workspace)
         return FDGS_EINVAL;
     if (a->sort_workspace_bytes < fdgs_raster_sort_workspace_bytes(R)) return FDGS_EWORKSPACE;
+    // FDGS_SORT=radix: the least-significant-digit radix sort over all R keys; otherwise the tile-binned sort
+    // (tile_sort.h) wherever it applies.  Both give the same keys, values and ranges.
+    const char* sort_env = getenv("FDGS_SORT");
+    if (!(sort_env && sort_env[0] == 'r')) {
+        const int rc = fdgs_tile_sort(a, (uint32_t*)a->sort_workspace + FDGS_RADIX_WS_WORDS,
+                                      a->sort_workspace_bytes / sizeof(uint32_t) - FDGS_RADIX_WS_WORDS, s);
+        if (rc != 1) return rc;
+    }
     int tile_bits = 0;
     while ((1 << tile_bits) < tiles) ++tile_bits;   // keys are < tiles << 32
     // With the frame's depth range (the first two words fdgs_raster_preprocess_fwd leaves in its scan workspace) the

@@ -26,9 +26,12 @@ def _run_oracle(c, with_grad):
     return ins, m2, color, radii, depth, aux
 
 
+@pytest.mark.parametrize("sort", ["tiles", "radix"])
 @pytest.mark.parametrize("name", ["small", "ragged", "deg0", "medium", "n256", "n2049", "n4096"])
-def test_forward_stages(name):
+def test_forward_stages(name, sort, monkeypatch):
+    """`sort`: the tile lists by binning + per-tile sort in LDS (the default) or by the radix sort over all keys."""
     from fdgs import rasterizer as fr
+    monkeypatch.setenv("FDGS_SORT", sort)
     c = rc.make_case(name)
     _, _, color, radii, depth, aux = _run_oracle(c, False)
     dev = torch.device("cuda:0")
@@ -66,6 +69,63 @@ def test_forward_stages(name):
     assert float((st.color.cpu() - color).abs().max()) <= IMG_TOL
     dtol = IMG_TOL * max(1.0, float(depth.abs().max()))
     assert float((st.depth.cpu() - depth).abs().max()) <= dtol
+
+
+@pytest.mark.parametrize("n,w,h,scale_mult,tied", [
+    (10000, 64, 48, 8.0, 0),         # 12 tiles, lists of a few thousand entries: the large workgroups' LDS path
+    (10000, 64, 48, 8.0, 2500),      # ... with 2500 Gaussians at one depth (ranked by id inside their depth field)
+    (30000, 32, 32, 8.0, 0),         # 4 tiles, lists beyond every LDS segment: sorted where they lie in memory
+    (30000, 32, 32, 8.0, 9000),
+    (3000, 200, 120, 1.0, 700),      # short lists with ties
+])
+def test_tile_binned_sort_long_lists_and_equal_depths(n, w, h, scale_mult, tied, monkeypatch):
+    """fdgs_raster_bin_sort by tile binning against the oracle's stable sort where the per-tile lists are long and
+    where many Gaussians share one depth (equal keys keep the Gaussian order).  The call is made on its own, on the
+    preprocess outputs of a forward pass that used the radix sort."""
+    import math
+    from fdgs import rasterizer as fr, scene_synth as ss, _lib
+    from fdgs._lib import lib, ptr
+    cam = ss.make_cameras(3, w, h)[1]
+    g = ss.GaussianParams(n, scale_mult=scale_mult, requires_grad=False)
+    means3D = g._xyz.clone()
+    if tied:
+        means3D[50:50 + tied] = means3D[50]
+    S = rr.Settings(h, w, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.ones(3), 1.0,
+                    cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center)
+    ins = dict(means3D=means3D, shs=g.get_features.contiguous(), opacities=torch.sigmoid(g._opacity),
+               scales=torch.exp(g._scaling), rotations=torch.nn.functional.normalize(g._rotation))
+    pre = rr.preprocess(ins["means3D"], ins["scales"], ins["rotations"], ins["opacities"], ins["shs"], S)
+    keys, vals, offsets = rr.build_keys(pre, S)
+    skeys, svals = rr.sort_keys(keys, vals)
+    gx, gy = rr.tile_grid(S)
+    ranges = rr.tile_ranges(skeys, gx * gy)
+    R = keys.numel()
+    if tied:
+        same = (skeys[1:] == skeys[:-1])
+        assert int(same.sum()) >= tied // 2, "the case is meant to have equal keys"
+
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("FDGS_SORT", "radix")
+    st = fr.rasterize_forward(ins["means3D"].to(dev), ins["shs"].to(dev), ins["opacities"].reshape(-1).to(dev),
+                              ins["scales"].to(dev), ins["rotations"].to(dev), _to_dev(S, dev), keep_keys=True)
+    torch.cuda.synchronize()
+    assert st.num_rendered == R and torch.equal(st.keys_sorted[:R].cpu(), skeys)
+    monkeypatch.setenv("FDGS_SORT", "tiles")
+    ws_bytes = lib.fdgs_raster_sort_workspace_bytes(R)
+    ka = torch.empty(R, device=dev, dtype=torch.int64)
+    va = torch.empty(R, device=dev, dtype=torch.int32)
+    ks = torch.zeros(R, device=dev, dtype=torch.int64)
+    vs = torch.zeros(R, device=dev, dtype=torch.int32)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    rg = torch.empty_like(st.ranges)
+    order = torch.empty_like(st.tile_order)
+    _lib.call("fdgs_raster_bin_sort", _lib.BinSortArgs(n, w, h, R, ptr(st.geom), ptr(st.point_offsets), ptr(ka), ptr(va),
+                                                       ptr(ks), ptr(vs), ptr(rg), ptr(ws), ws_bytes, 0, 0, ptr(order)))
+    torch.cuda.synchronize()
+    assert torch.equal(ks.cpu(), skeys)
+    assert torch.equal(vs.cpu(), svals)
+    assert torch.equal(rg.cpu(), ranges)
+    assert torch.equal(torch.sort(order.cpu().long())[0], torch.arange(gx * gy))
 
 
 def test_scan_in_two_launches_gives_the_same_lists(monkeypatch):
