@@ -98,7 +98,7 @@ __device__ __forceinline__ void ts_scan_totals(uint32_t* __restrict__ slot, cons
 // The walk of duplicateWithKeys (raster_preprocess.hip): a wave takes 64 consecutive Gaussians and visits their list
 // positions together, lane l the positions first + l, first + l + 64, ...; the owner of a position is found by binary
 // search over the wave's 64 scan values in LDS, so a large splat is shared by all lanes instead of holding one.
-// SCATTER: workgroup 0 orders the tiles; workgroup b + 1 walks chunk b.
+// SCATTER: one workgroup more than there are chunks: the last one orders the tiles.
 template <bool SCATTER>
 __global__ void __launch_bounds__(TS_WALK_THREADS)
 tile_walk_kernel(int n, int per_group, const float* __restrict__ geom, const uint32_t* __restrict__ offsets, int gx,
@@ -115,14 +115,22 @@ tile_walk_kernel(int n, int per_group, const float* __restrict__ geom, const uin
     uint32_t* __restrict__ s_depth = s_y0 + TS_WALK_WAVES * 64;
     uint32_t* __restrict__ s_wsum = s_depth + TS_WALK_WAVES * 64;         // [waves]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (SCATTER && blockIdx.x == 0) {
+    if (SCATTER && blockIdx.x == gridDim.x - 1) {
         // first positions in slot[], then the tile ids by decreasing length with (tile, first position, length) each
         ts_scan_totals(slot, totals, tiles, s_wsum, nullptr, nullptr);
         __syncthreads();
         tile_order_block<TS_WALK_THREADS>(nullptr, totals, order, tiles, s_end, s_end + ORDER_CLASSES, slot, desc);
         return;
     }
-    const int chunk = SCATTER ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    // SCATTER: consecutive chunks go to workgroups of one XCD (workgroup j runs on XCD j mod 8).  A tile's segment is
+    // filled chunk after chunk, so each part of it is then written from one XCD and its 8-byte stores meet in that
+    // XCD's L2 as whole lines; spread over all XCDs, every line is written back in pieces by up to eight L2s.
+    // (Only the speed depends on where workgroups run.)
+    int chunk = (int)blockIdx.x;
+    if (SCATTER) {
+        const int G = (int)gridDim.x - 1, x = chunk & 7;
+        chunk = x * (G >> 3) + min(x, G & 7) + (chunk >> 3);
+    }
     uint32_t* __restrict__ row = table + (size_t)chunk * tiles;
 
     // the wave's first group of Gaussians is requested before the histogram is set up
