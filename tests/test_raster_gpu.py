@@ -77,6 +77,8 @@ def test_forward_stages(name, sort, monkeypatch):
     (30000, 32, 32, 8.0, 0),         # 4 tiles, lists beyond every LDS segment: sorted where they lie in memory
     (30000, 32, 32, 8.0, 9000),
     (3000, 200, 120, 1.0, 700),      # short lists with ties
+    (3000, 3840, 2160, 12.0, 0),     # 32400 tiles: the walks' per-tile counters take 130 KB of LDS
+    (3000, 2944, 2944, 12.0, 0),     # 33856 tiles, more than the counters hold: the call falls back to the radix sort
 ])
 def test_tile_binned_sort_long_lists_and_equal_depths(n, w, h, scale_mult, tied, monkeypatch):
     """fdgs_raster_bin_sort by tile binning against the oracle's stable sort where the per-tile lists are long and
