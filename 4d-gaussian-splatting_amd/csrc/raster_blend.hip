@@ -24,25 +24,26 @@ __device__ __forceinline__ float bcast(float v, int lane) {
 }
 
 // Turns the four survivor masks of a batch into four compacted lists of batch positions in the wave's LDS area
-// (list g, slot k = the k-th set bit of mask g): the inner loop then finds a row's next survivor with one LDS byte
-// read instead of scalar bit scans on four 64-bit masks (the scalar unit is shared by the CU's four SIMDs and was
-// the bottleneck with them).  Returns the longest list's length; `mine` = the length of this lane's row's list.
+// (slot k of list g = the k-th set bit of mask g, at byte 4 k + g): the inner loop then finds a row's next survivor
+// with one LDS byte read instead of scalar bit scans on four 64-bit masks (the scalar unit is shared by the CU's four
+// SIMDs and was the bottleneck with them).  Every slot is first set to the null record, so a row whose list is
+// shorter than the longest one reads null records for the rest of the batch's steps without a test.
+// Returns the longest list's length.
 __device__ __forceinline__ int build_lists(unsigned char* __restrict__ lists, unsigned long long m0,
                                            unsigned long long m1, unsigned long long m2, unsigned long long m3,
-                                           int lane, int row, int& mine) {
+                                           int lane) {
     const uint32_t lo0 = (uint32_t)m0, hi0 = (uint32_t)(m0 >> 32), lo1 = (uint32_t)m1, hi1 = (uint32_t)(m1 >> 32);
     const uint32_t lo2 = (uint32_t)m2, hi2 = (uint32_t)(m2 >> 32), lo3 = (uint32_t)m3, hi3 = (uint32_t)(m3 >> 32);
     const uint32_t r0 = __builtin_amdgcn_mbcnt_hi(hi0, __builtin_amdgcn_mbcnt_lo(lo0, 0u));   // set bits below this lane
     const uint32_t r1 = __builtin_amdgcn_mbcnt_hi(hi1, __builtin_amdgcn_mbcnt_lo(lo1, 0u));
     const uint32_t r2 = __builtin_amdgcn_mbcnt_hi(hi2, __builtin_amdgcn_mbcnt_lo(lo2, 0u));
     const uint32_t r3 = __builtin_amdgcn_mbcnt_hi(hi3, __builtin_amdgcn_mbcnt_lo(lo3, 0u));
-    if ((m0 >> lane) & 1ull) lists[r0] = (unsigned char)lane;
-    if ((m1 >> lane) & 1ull) lists[64 + r1] = (unsigned char)lane;
-    if ((m2 >> lane) & 1ull) lists[128 + r2] = (unsigned char)lane;
-    if ((m3 >> lane) & 1ull) lists[192 + r3] = (unsigned char)lane;
+    reinterpret_cast<uint32_t*>(lists)[lane] = 0x01010101u * (uint32_t)BL_NULL;     // a wave's LDS accesses run in order
+    if ((m0 >> lane) & 1ull) lists[4 * r0 + 0] = (unsigned char)lane;
+    if ((m1 >> lane) & 1ull) lists[4 * r1 + 1] = (unsigned char)lane;
+    if ((m2 >> lane) & 1ull) lists[4 * r2 + 2] = (unsigned char)lane;
+    if ((m3 >> lane) & 1ull) lists[4 * r3 + 3] = (unsigned char)lane;
     const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-    const uint32_t packed = (uint32_t)(n0 | (n1 << 8) | (n2 << 16) | (n3 << 24));
-    mine = (int)((packed >> (8 * row)) & 0xffu);
     return max(max(n0, n1), max(n2, n3));
 }
 
@@ -146,10 +147,9 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
         if ((live & 0xffff0000ull) == 0ull) m1 = 0ull;
         if ((live & 0xffff00000000ull) == 0ull) m2 = 0ull;
         if ((live & 0xffff000000000000ull) == 0ull) m3 = 0ull;
-        int mine;
-        const int steps = build_lists(mylist, m0, m1, m2, m3, lane, row, mine);
+        const int steps = build_lists(mylist, m0, m1, m2, m3, lane);
         for (int t = 0; t < steps; ++t) {
-            const int j = t < mine ? (int)mylist[64 * row + t] : BL_NULL;
+            const int j = (int)mylist[4 * t + row];
             const float4 c0 = my[j * 2 + 0], c1 = my[j * 2 + 1];
             const float2 c2 = my2[j];
             const float dx = c0.x - pxf, dy = c0.y - pyf;
@@ -236,7 +236,7 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     }
     const float tb = -T_final * (a.bg[0] * dLr + a.bg[1] * dLg + a.bg[2] * dLb);
     float T = T_final;
-    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, last_alpha = 0.f, last_r = 0.f, last_g = 0.f, last_b = 0.f;
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
 
     // last contributor of each row's sixteen pixels, and of the wave
     int row_last = ncon;
@@ -296,40 +296,36 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
         // entries behind a row's last contributor cannot contribute to it
         m0 &= __ballot(pos < last0); m1 &= __ballot(pos < last1);
         m2 &= __ballot(pos < last2); m3 &= __ballot(pos < last3);
-        int mine;
-        const int steps = build_lists(mylist, m0, m1, m2, m3, lane, row, mine);
+        const int steps = build_lists(mylist, m0, m1, m2, m3, lane);
+        const int jmin = hi - 1 - ncon;       // entry j of the batch is list position hi - 1 - j: before the pixel's last contributor <=> j > jmin
         for (int t = 0; t < steps; ++t) {
-            const int j = t < mine ? (int)mylist[64 * row + t] : BL_NULL;
+            const int j = (int)mylist[4 * t + row];
             const float4 c0 = my[j * 3 + 0], c1 = my[j * 3 + 1];
-            const int p = hi - 1 - j;
             const float o = c1.y;
             const float dx = c0.x - pxf, dy = c0.y - pyf;
             const float u = c0.z * dx, w = c1.x * dy, bdx = c0.w * dx;
             const float power = 0.5f * (u * dx + w * dy) + bdx * dy;      // log2(e) x the exponent
             const float G = __builtin_amdgcn_exp2f(power);
             const float alpha = fminf(FDGS_ALPHA_MAX, o * G);
-            const bool contrib = (p < ncon) && power <= 0.0f && alpha >= FDGS_ALPHA_MIN;
+            const bool contrib = (j > jmin) && power <= 0.0f && alpha >= FDGS_ALPHA_MIN;
             if (__ballot(contrib) == 0ull) continue;
             // No divergent branch: a lane that does not contribute runs the same arithmetic with alpha = 0 and
-            // G = 0, which leaves its state unchanged bit for bit (T * rcp(1) = T; the pending (last_alpha,
-            // last colour) pair is folded into acc now instead of at the next contributor - the same single
-            // expression on the same operands - and the pair it leaves, alpha 0, folds as 0 * c + 1 * acc = acc)
-            // and makes all nine of its partial sums exact zeros.
+            // G = 0, which leaves its state unchanged bit for bit (T * rcp(1) = T; the colour behind folds as
+            // 0 * c + 1 * acc = acc) and makes all nine of its partial sums exact zeros.
             const float4 c2 = my[j * 3 + 2];
             const float al = contrib ? alpha : 0.0f;
             const float Ge = contrib ? G : 0.0f;
             const float cr = c1.z, cg = c1.w, cb = c2.x;
-            const float inv_one_m = __builtin_amdgcn_rcpf(1.0f - al);   // 1 ulp; alpha <= 0.99
+            const float one_m = 1.0f - al;
+            const float inv_one_m = __builtin_amdgcn_rcpf(one_m);       // 1 ulp; alpha <= 0.99
             T = T * inv_one_m;
             const float wgt = al * T;
-            const float keep = 1.0f - last_alpha;
-            acc_r = last_alpha * last_r + keep * acc_r;
-            acc_g = last_alpha * last_g + keep * acc_g;
-            acc_b = last_alpha * last_b + keep * acc_b;
-            last_r = cr; last_g = cg; last_b = cb;
+            // acc = the blended colour behind this entry; the entry itself joins it for the ones in front
             float dL_dalpha = (cr - acc_r) * dLr + (cg - acc_g) * dLg + (cb - acc_b) * dLb;
+            acc_r = al * cr + one_m * acc_r;
+            acc_g = al * cg + one_m * acc_g;
+            acc_b = al * cb + one_m * acc_b;
             const float v_r = wgt * dLr, v_g = wgt * dLg, v_b = wgt * dLb;
-            last_alpha = al;
             dL_dalpha = dL_dalpha * T + tb * inv_one_m;
             const float v_o = Ge * dL_dalpha;
             const float g = o * v_o;                                    // dL/d(exponent), in the exponent's own scale
