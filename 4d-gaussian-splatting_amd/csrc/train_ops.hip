@@ -290,3 +290,27 @@ extern "C" int fdgs_plane_regulation(const fdgs_plane_reg_args* a, void* stream)
     }
     return FDGS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// 8-bit frames (render.py:47,78 of the reference: to8b + transpose to H, W, C).  One thread per pixel: C coalesced
+// plane reads, C consecutive bytes written.  HBM-bound: 4 C bytes read, C written per pixel.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+image_to8b_kernel(const float* __restrict__ img, uint8_t* __restrict__ out, int C, int64_t plane) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= plane) return;
+    for (int c = 0; c < C; ++c) {
+        const float v = fminf(fmaxf(img[c * plane + p], 0.0f), 1.0f);      // a NaN gives 0
+        out[p * C + c] = (uint8_t)(int)(255.0f * v);
+    }
+}
+
+extern "C" int fdgs_image_to8b(const float* image_chw, uint8_t* out_hwc, int32_t channels, int32_t height,
+                               int32_t width, void* stream) {
+    if (channels <= 0 || height <= 0 || width <= 0 || !image_chw || !out_hwc) return FDGS_EINVAL;
+    const int64_t plane = (int64_t)height * width;
+    hipLaunchKernelGGL(image_to8b_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       image_chw, out_hwc, channels, plane);
+    FDGS_CHECK_LAUNCH();
+    return FDGS_OK;
+}

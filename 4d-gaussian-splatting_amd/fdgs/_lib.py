@@ -209,6 +209,7 @@ SYMBOLS = {
     "fdgs_l1_loss_fwd": (C.c_int, [C.POINTER(L1FwdArgs), c_p]),
     "fdgs_l1_loss_bwd": (C.c_int, [C.POINTER(L1BwdArgs), c_p]),
     "fdgs_l1_loss_fwd_static": (C.c_int, [C.POINTER(L1FwdArgs), c_p]),
+    "fdgs_image_to8b": (C.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p]),
     "fdgs_densify_stats": (C.c_int, [C.POINTER(DensifyStatsArgs), c_p]),
     "fdgs_plane_reg_partials": (c_sz, [c_i32]),
     "fdgs_plane_regulation": (C.c_int, [C.POINTER(PlaneRegArgs), c_p]),
@@ -227,7 +228,7 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 def _load():

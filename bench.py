@@ -411,7 +411,7 @@ def main():
         batch8 = args.batch8_steps / (time.perf_counter() - t3)
 
     # inference-only legs: deformation + forward rasterizer, frames strided over ranks, no collective
-    fps = fps_d2h = None
+    fps = fps_d2h = fps_d2h_host = None
     if args.render_frames > 0:
         import numpy as np
         frames = list(range(rank, args.render_frames, world))
@@ -424,18 +424,34 @@ def main():
                 render(cams[20], g, deforms, bg)
             sync()
             fps = args.render_frames / max_over_ranks(time.perf_counter() - t1)
-            # the reference's own FPS figure (render.py:74-89) includes, per frame, the copy of the float image
-            # to the host and its 8-bit conversion there (render.py:47,78)
-            def to8b(x):
-                return (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8)
-            images = [to8b(render(cams[20], g, deforms, bg)["render"]).transpose(1, 2, 0)]
+            # the reference's own FPS figure (render.py:74-89) includes, per frame, the 8-bit [H,W,3] copy of the image
+            # on the host.  (a) fdgs.playback.FrameSink: conversion on the device, 3 bytes per pixel copied on a
+            # second stream into pinned memory (identical bytes, tests/test_render_gpu.py); (b) the reference's
+            # literal host code: the float image copied and converted by numpy while the GPU waits.
+            from fdgs.playback import FrameSink
+            sink = FrameSink(len(frames) + 1, args.height, args.width, device=dev)
+            sink.push(render(cams[20], g, deforms, bg)["render"])
             sync()
             t1 = time.perf_counter()
             for f in frames:
                 cams[20].time = f / 300.0
-                images.append(to8b(render(cams[20], g, deforms, bg)["render"]).transpose(1, 2, 0))
+                sink.push(render(cams[20], g, deforms, bg)["render"])
+            images = sink.frames()
             sync()
             fps_d2h = args.render_frames / max_over_ranks(time.perf_counter() - t1)
+            del images, sink
+
+            def to8b(x):
+                return (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8)
+            host_frames = frames[:max(1, min(len(frames), 60))]
+            images = [to8b(render(cams[20], g, deforms, bg)["render"]).transpose(1, 2, 0)]
+            sync()
+            t1 = time.perf_counter()
+            for f in host_frames:
+                cams[20].time = f / 300.0
+                images.append(to8b(render(cams[20], g, deforms, bg)["render"]).transpose(1, 2, 0))
+            sync()
+            fps_d2h_host = len(host_frames) * world / max_over_ranks(time.perf_counter() - t1)
             del images
 
     # last leg of an N-rank run: the SAME batch of B views on rank 0 alone (no exchange step), the one-GPU point of
@@ -518,6 +534,7 @@ def main():
             "speedup_over_one_gpu": (args.steps / elapsed / one_gpu) if one_gpu else None,
             "render_fps": fps,
             "render_fps_with_d2h": fps_d2h,
+            "render_fps_with_d2h_host_conversion": fps_d2h_host,
             "kernel_ms": per_call,
             # deformation MLP, forward + backward: 3 x 187,136 flop per point in fp32 semantics.  The split mode
             # issues six bf16 MFMA terms per product: issued bf16 flop = 6 x that, against the dense bf16 peak;

@@ -373,6 +373,15 @@ int fdgs_l1_loss_bwd(const fdgs_l1_bwd_args* a, void* stream);
 #define FDGS_L1_STATIC_MAX_N ((int64_t)FDGS_L1_STATIC_MAX_PARTIALS * 4096)      /* 67,108,864 floats */
 int fdgs_l1_loss_fwd_static(const fdgs_l1_fwd_args* a, void* stream);
 
+/* ---- 8-bit frames for playback: the conversion the reference applies to every rendered frame on the host,
+ * to8b = (255 * np.clip(x, 0, 1)).astype(np.uint8) followed by transpose(1, 2, 0) (render.py:47,78), done on the
+ * device, so that a frame leaves the GPU as C * H * W bytes instead of four times that in floats.
+ * out[(y * W + x) * C + c] = (uint8) trunc(255.0f * min(max(image[c][y][x], 0), 1)): one fp32 multiply and a
+ * truncation, bit for bit what numpy computes for finite inputs (a NaN pixel gives 0 here; numpy leaves it
+ * undefined).                                                                                                 */
+int fdgs_image_to8b(const float* image_chw, uint8_t* out_hwc, int32_t channels, int32_t height, int32_t width,
+                    void* stream);
+
 /* ---- densification statistics of one iteration (src/runner/fdgs_trainer.py:181-182,
  * src/model/gaussian_model.py:182-184): for every Gaussian with radii > 0,
  * max_radii2D = max(max_radii2D, radii), xyz_gradient_accum += |viewspace_grad.xy|, denom += 1. */

@@ -186,3 +186,57 @@ def test_saved_scene_plays_back_through_the_hip_path(tmp_path):
         assert torch.cuda.memory_allocated() <= base + (1 << 20)
     finally:
         gc.enable()
+
+
+def test_frames_to8b_match_numpy():
+    """fdgs.playback.FrameSink against the reference's host-side conversion (render.py:47,78), bit for bit, over more
+    frames than it has staging buffers, with values outside [0, 1] and on the k / 255 steps."""
+    import numpy as np
+    from fdgs.playback import FrameSink
+    dev = torch.device("cuda:0")
+    H, W = 37, 53
+    gen = torch.Generator().manual_seed(5)
+    frames = []
+    for i in range(5):
+        x = torch.rand(3, H, W, generator=gen) * 1.4 - 0.2
+        x[0, 0, :] = torch.arange(W, dtype=torch.float32) / 255.0           # exact steps
+        x[1, 1, :] = (torch.arange(W, dtype=torch.float32) + 200) / 255.0
+        x[2, 2, :4] = torch.tensor([0.0, 1.0, -0.0, 0.99999994])
+        frames.append(x)
+    sink = FrameSink(len(frames), H, W, device=dev)
+    for x in frames:
+        sink.push(x.to(dev))
+    out = sink.frames()
+    assert len(out) == len(frames)
+    for x, got in zip(frames, out):
+        ref = (255 * np.clip(x.numpy(), 0, 1)).astype(np.uint8).transpose(1, 2, 0)
+        assert got.dtype == np.uint8 and got.shape == (H, W, 3)
+        assert np.array_equal(got, ref)
+    with pytest.raises(IndexError):
+        sink.push(frames[0].to(dev))
+
+
+def test_render_sequence_gives_the_frames_of_the_host_loop():
+    """render_sequence (render.py:74-79) against render() + the host conversion, frame by frame."""
+    import numpy as np
+    from fdgs import scene_synth as ss
+    from fdgs.deformation import DeformationFields
+    from fdgs.playback import render_sequence
+    from fdgs.renderer import render
+    from fdgs.train_step import DeformHolder
+    dev = torch.device("cuda:0")
+    g = ss.GaussianParams(4000, device=dev, scale_mult=3.0, requires_grad=False)
+    torch.manual_seed(3)
+    net = DeformationFields(ss.DYNERF_NET_KWARGS)
+    ss.perturb_deformation_(net)
+    net = net.to(dev)
+    deforms = DeformHolder(net)
+    cams = ss.make_cameras(4, 96, 64, device=dev)
+    bg = torch.ones(3, device=dev)
+    images, renders = render_sequence(cams, g, deforms, bg, keep_renders=True)
+    assert len(images) == len(cams) == len(renders)
+    with torch.no_grad():
+        for cam, img in zip(cams, images):
+            x = render(cam, g, deforms, bg)["render"]
+            ref = (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8).transpose(1, 2, 0)
+            assert np.array_equal(img, ref)
