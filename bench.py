@@ -425,21 +425,24 @@ def main():
             sync()
             fps = args.render_frames / max_over_ranks(time.perf_counter() - t1)
             # the reference's own FPS figure (render.py:74-89) includes, per frame, the 8-bit [H,W,3] copy of the image
-            # on the host.  (a) fdgs.playback.FrameSink: conversion on the device, 3 bytes per pixel copied on a
-            # second stream into pinned memory (identical bytes, tests/test_render_gpu.py); (b) the reference's
-            # literal host code: the float image copied and converted by numpy while the GPU waits.
-            from fdgs.playback import FrameSink
-            sink = FrameSink(len(frames) + 1, args.height, args.width, device=dev)
-            sink.push(render(cams[20], g, deforms, bg)["render"])
+            # on the host.  (a) fdgs.playback.render_sequence: conversion on the device, 3 bytes per pixel copied on a
+            # copy stream into pinned memory (identical bytes, tests/test_render_gpu.py; allocation of the pinned
+            # array included); (b) the reference's literal host code: the float
+            # image copied and converted by numpy while the GPU waits.
+            import copy
+            from fdgs.playback import render_sequence
+            views = []
+            for f in frames:
+                v = copy.copy(cams[20])
+                v.time = f / 300.0
+                views.append(v)
+            render_sequence(views[:2], g, deforms, bg)
             sync()
             t1 = time.perf_counter()
-            for f in frames:
-                cams[20].time = f / 300.0
-                sink.push(render(cams[20], g, deforms, bg)["render"])
-            images = sink.frames()
+            images, _ = render_sequence(views, g, deforms, bg)
             sync()
             fps_d2h = args.render_frames / max_over_ranks(time.perf_counter() - t1)
-            del images, sink
+            del images
 
             def to8b(x):
                 return (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8)
