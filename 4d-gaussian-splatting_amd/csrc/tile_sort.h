@@ -360,16 +360,37 @@ __device__ __forceinline__ void ts_ce8(uint32_t (&x)[8], int hi_rb, int lo_rb) {
     }
 }
 
+// Word offset of the elements of "virtual thread" tid + THREADS * v from those of thread tid, for the bit triple that
+// starts at bit sk: a thread-index bit at or above sk is element-index bit + 3, one below sk is the same element bit;
+// all of them are element bits >= 6, where ts_pa is linear (2^p + 2^(p-3) words per bit).
+template <int THREADS>
+__device__ __forceinline__ int ts_voff(int sk, int v) {
+    int tb = 0;
+    while ((1 << tb) < THREADS) ++tb;               // constant-folded
+    int off = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if ((v >> j) & 1) {
+            const int p = tb + j, pe = p >= sk ? p + 3 : p;
+            off += (1 << pe) + (1 << (pe - 3));
+        }
+    }
+    return off;
+}
+
 // Sorts w[ts_pa(0 .. P-1)] ascending, P = 2^lp >= 8.  The caller synchronises before (the fill) and after.
-// With P / 8 <= THREADS every thread keeps the same eight elements per bit triple in all merges and their LDS
-// addresses are computed once (computed per trip they were three quarters of the kernel's vector instructions).
+// With P / 8 <= TS_VMAX * THREADS every thread keeps the same element octets per bit triple in all merges and their
+// LDS addresses are computed once (computed per trip they were three quarters of the kernel's vector instructions);
+// a thread's second octet lies a fixed number of words behind its first.
 // The triples are bits 0-2, 3-5, ... and, at the top, the last three bits lp-3 .. lp-1, which may overlap the triple
 // below: that one then leaves the shared bits to the top triple.
+#define TS_VMAX 2                                   // element octets per thread and triple on the fast path
 template <int THREADS>
 __device__ __forceinline__ void ts_sort_words(uint32_t* __restrict__ w, int lp) {
     const int P = 1 << lp;
-    if ((P >> 3) <= THREADS) {
+    if ((P >> 3) <= THREADS * TS_VMAX) {
         const int T = threadIdx.x;
+        const int V = (P >> 3) > THREADS ? (P >> 3) / THREADS : 1;       // octets per thread: a power of two
         const bool act = T < (P >> 3);
         const int np = (lp + 2) / 3;                    // bit triples: 1 .. TS_TRIPLES (P <= 2^15)
         uint32_t* ap[TS_TRIPLES][8];
@@ -378,25 +399,33 @@ __device__ __forceinline__ void ts_sort_words(uint32_t* __restrict__ w, int lp) 
         for (int k = 0; k < TS_TRIPLES; ++k) {
             const int sk = (k >= np - 1) ? lp - 3 : 3 * k;
             sft[k] = sk;
-            const int ibase = ((T >> sk) << (sk + 3)) | (T & ((1 << sk) - 1));
+            if (k < np) {                               // uniform: the unused triples cost nothing
+                const int ibase = ((T >> sk) << (sk + 3)) | (T & ((1 << sk) - 1));
 #pragma unroll
-            for (int m = 0; m < 8; ++m) ap[k][m] = w + ts_pa((ibase | (m << sk)) & (P - 1));
+                for (int m = 0; m < 8; ++m) ap[k][m] = w + ts_pa((ibase | (m << sk)) & (P - 1));
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) ap[k][m] = w;
+            }
         }
         uint32_t x[8];
         if (act) {                                      // merges 1-3: every aligned run of eight, inside a thread
+            for (int v = 0; v < V; ++v) {
+                const int d = ts_voff<THREADS>(0, v), Tv = T + THREADS * v;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) x[m] = *ap[0][m] ^ (0u - (uint32_t)((m >> 1) & 1));   // bit 1 set: descending
+                for (int m = 0; m < 8; ++m) x[m] = ap[0][m][d] ^ (0u - (uint32_t)((m >> 1) & 1));   // bit 1 set: descending
 #pragma unroll
-            for (int lk = 1; lk <= 3; ++lk) {
-                ts_ce8(x, lk - 1, 0);
+                for (int lk = 1; lk <= 3; ++lk) {
+                    ts_ce8(x, lk - 1, 0);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int i = (T << 3) | m;
-                    x[m] ^= 0u - (uint32_t)(((i >> lk) ^ (i >> (lk + 1))) & 1);
+                    for (int m = 0; m < 8; ++m) {
+                        const int i = (Tv << 3) | m;
+                        x[m] ^= 0u - (uint32_t)(((i >> lk) ^ (i >> (lk + 1))) & 1);
+                    }
                 }
-            }
 #pragma unroll
-            for (int m = 0; m < 8; ++m) *ap[0][m] = x[m];
+                for (int m = 0; m < 8; ++m) ap[0][m][d] = x[m];
+            }
         }
         for (int lk = 4; lk <= lp; ++lk) {
 #pragma unroll
@@ -408,16 +437,19 @@ __device__ __forceinline__ void ts_sort_words(uint32_t* __restrict__ w, int lp) 
                 if (top < sk) continue;                 // the merge does not reach this triple
                 ts_trip_sync<THREADS>();
                 if (act) {
+                    for (int v = 0; v < V; ++v) {
+                        const int d = ts_voff<THREADS>(sk, v), Tv = T + THREADS * v;
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) x[m] = *ap[k][m];
-                    ts_ce8(x, top - sk, 0);
-                    if (k == 0) {                       // the merge ends here: the complement moves from bit lk to lk + 1
-                        const uint32_t flip = 0u - (uint32_t)(((T >> (lk - 3)) ^ (T >> (lk - 2))) & 1);
+                        for (int m = 0; m < 8; ++m) x[m] = ap[k][m][d];
+                        ts_ce8(x, top - sk, 0);
+                        if (k == 0) {                   // the merge ends here: the complement moves from bit lk to lk + 1
+                            const uint32_t flip = 0u - (uint32_t)(((Tv >> (lk - 3)) ^ (Tv >> (lk - 2))) & 1);
 #pragma unroll
-                        for (int m = 0; m < 8; ++m) x[m] ^= flip;
+                            for (int m = 0; m < 8; ++m) x[m] ^= flip;
+                        }
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) ap[k][m][d] = x[m];
                     }
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) *ap[k][m] = x[m];
                 }
             }
         }
@@ -529,7 +561,7 @@ tile_sort_kernel(uint64_t* __restrict__ binned, const uint4* __restrict__ desc, 
         for (int k = 0; k < ITEMS; ++k) {
             const int i = threadIdx.x + k * THREADS;
             dv[k] = 0u;
-            if (i < n) {
+            if (k * THREADS < n && i < n) {             // the first test is uniform: short segments skip the rest
                 dv[k] = (uint32_t)(binned[first + i] >> 32);
                 dlo = min(dlo, dv[k]);
                 dhi = max(dhi, dv[k]);
@@ -548,7 +580,8 @@ tile_sort_kernel(uint64_t* __restrict__ binned, const uint4* __restrict__ desc, 
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             const int i = threadIdx.x + k * THREADS;
-            if (i < P) word[ts_pa(i)] = i < n ? ((((dv[k] - dmin) >> shift) << lp) | (uint32_t)i) : 0xffffffffu;
+            if (k * THREADS < P && i < P)
+                word[ts_pa(i)] = i < n ? ((((dv[k] - dmin) >> shift) << lp) | (uint32_t)i) : 0xffffffffu;
         }
         __syncthreads();
         ts_sort_words<THREADS>(word, lp);
@@ -624,11 +657,11 @@ int fdgs_tile_sort(const fdgs_binsort_args* a, uint32_t* ws, size_t ws_words, hi
                            tiles, 0, a->keys_sorted, a->vals_sorted);
     } else if (mean <= 640) {
         cap = 2048;
-        hipLaunchKernelGGL((tile_sort_kernel<256, 2048, false, false>), dim3(tiles), dim3(256), 0, s, binned, desc,
+        hipLaunchKernelGGL((tile_sort_kernel<128, 2048, false, false>), dim3(tiles), dim3(128), 0, s, binned, desc,
                            tiles, 0, a->keys_sorted, a->vals_sorted);
     } else {
         cap = 4096;
-        hipLaunchKernelGGL((tile_sort_kernel<512, 4096, false, false>), dim3(tiles), dim3(512), 0, s, binned, desc,
+        hipLaunchKernelGGL((tile_sort_kernel<256, 4096, false, false>), dim3(tiles), dim3(256), 0, s, binned, desc,
                            tiles, 0, a->keys_sorted, a->vals_sorted);
     }
     FDGS_CHECK_LAUNCH();
