@@ -651,11 +651,11 @@ int fdgs_tile_sort(const fdgs_binsort_args* a, uint32_t* ws, size_t ws_words, hi
     // workgroups then walk the tiles longest first for the longer segments and leave when the lengths fall below cap.
     const int64_t mean = a->num_rendered / tiles;
     int cap;
-    if (mean <= 300) {
+    if (mean <= 512) {
         cap = 1024;
         hipLaunchKernelGGL((tile_sort_kernel<64, 1024, false, false>), dim3(tiles), dim3(64), 0, s, binned, desc,
                            tiles, 0, a->keys_sorted, a->vals_sorted);
-    } else if (mean <= 640) {
+    } else if (mean <= 1024) {
         cap = 2048;
         hipLaunchKernelGGL((tile_sort_kernel<128, 2048, false, false>), dim3(tiles), dim3(128), 0, s, binned, desc,
                            tiles, 0, a->keys_sorted, a->vals_sorted);
