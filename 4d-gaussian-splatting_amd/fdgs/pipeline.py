@@ -224,38 +224,46 @@ class ViewPipeline:
             return _lib.BinSortArgs(N, W, H, 0, ptr(self.geom), ptr(self.point_offsets), ptr(self.keys_a),
                                     ptr(self.vals_a), ptr(self.keys_b), ptr(self.vals_b), ptr(self.ranges),
                                     ptr(self.sort_ws), self.sort_ws_bytes, 0, 0, ptr(self.tile_order))
-        # everything the host can do before it knows R is done before it waits: the GPU idles from the end of the
-        # scan until the first launch after the wait
+        # everything the host can do before it knows R is done before it waits - the argument blocks of all five calls
+        # that follow included (a block is a dozen pointer look-ups in Python): the GPU idles from the end of the scan
+        # until the first launch after the wait, and between short kernels while the host is still catching up
+        n_img = 3 * H * W
+        self._scalar_turn ^= 1
+        loss_buf, psnr_buf = self._scalars[self._scalar_turn]
+        d_m3 = S["means3D"] if fine else S["xyz"]
+
+        def list_args():
+            plist = ptr(self.vals_b)
+            return (_lib.BlendFwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.color),
+                                      ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib), ptr(self.tile_order)),
+                    # dgeom: zero from its allocation, re-zeroed by preprocess_bwd below
+                    _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),
+                                      ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom),
+                                      ptr(self.tile_order)))
         bs = binsort_args() if self.capacity > 0 else None
+        bf, bb = list_args() if self.capacity > 0 else (None, None)
+        # the view's loss is this term alone: its gradient comes out of the same pass over the two images
+        l1 = _lib.L1FwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(loss_buf), ptr(self.l1_partial),
+                            ptr(psnr_buf) if want_psnr else None, ptr(self.grad_image), ptr(loss_term))
+        pb = _lib.PreprocessBwdArgs(N, sh_degree, W, H, tanx, tany, 1.0, ptr(vm), ptr(pm), ptr(cp), ptr(m3),
+                                    ptr(scales), ptr(rots), ptr(shs), None, None, ptr(self.geom), ptr(self.dgeom),
+                                    ptr(d_m3), ptr(S["means2D"]), ptr(S["scaling"]), ptr(S["rotation"]),
+                                    ptr(S["opacity"]), ptr(S["shs"]), None, None, acts, 1)
         ready.synchronize()
         dmin, dmax, R = (int(v) & 0xffffffff for v in self.r_host.tolist())
         _rasterizer.LAST_NUM_RENDERED = R
         if bs is None or R > self.capacity:
             self._list_buffers(max(R, 1), dev)
             bs = binsort_args()
+            bf, bb = list_args()
         bs.num_rendered, bs.depth_bits_min, bs.depth_bits_max = R, dmin, dmax
+        if R == 0:
+            bf.point_list = bb.point_list = None
         _lib.call("fdgs_raster_bin_sort", bs)
-        plist = ptr(self.vals_b) if R > 0 else None
-        _lib.call("fdgs_raster_blend_fwd",
-                  _lib.BlendFwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.color),
-                                    ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib), ptr(self.tile_order)))
-        n_img = 3 * H * W
-        # the view's loss is this term alone: its gradient comes out of the same pass over the two images
-        self._scalar_turn ^= 1
-        loss_buf, psnr_buf = self._scalars[self._scalar_turn]
-        _lib.call("fdgs_l1_loss_fwd", _lib.L1FwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(loss_buf),
-                                                     ptr(self.l1_partial), ptr(psnr_buf) if want_psnr else None,
-                                                     ptr(self.grad_image), ptr(loss_term)))
-        _lib.call("fdgs_raster_blend_bwd",      # dgeom: zero from its allocation, re-zeroed by preprocess_bwd below
-                  _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),
-                                    ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom),
-                                    ptr(self.tile_order)))
-        d_m3 = S["means3D"] if fine else S["xyz"]
-        _lib.call("fdgs_raster_preprocess_bwd",
-                  _lib.PreprocessBwdArgs(N, sh_degree, W, H, tanx, tany, 1.0, ptr(vm), ptr(pm), ptr(cp), ptr(m3),
-                                         ptr(scales), ptr(rots), ptr(shs), None, None, ptr(self.geom), ptr(self.dgeom),
-                                         ptr(d_m3), ptr(S["means2D"]), ptr(S["scaling"]), ptr(S["rotation"]),
-                                         ptr(S["opacity"]), ptr(S["shs"]), None, None, acts, 1))
+        _lib.call("fdgs_raster_blend_fwd", bf)
+        _lib.call("fdgs_l1_loss_fwd", l1)
+        _lib.call("fdgs_raster_blend_bwd", bb)
+        _lib.call("fdgs_raster_preprocess_bwd", pb)
         out = ViewGrads()
         early = S
         pending = None

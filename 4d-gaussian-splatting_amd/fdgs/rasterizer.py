@@ -102,6 +102,16 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
                 torch.empty(cap, device=dev, dtype=torch.int64), torch.empty(cap, device=dev, dtype=torch.int32),
                 torch.empty(ws_bytes, device=dev, dtype=torch.uint8), ws_bytes)
     bufs = list_buffers(_LIST_CAPACITY) if _LIST_CAPACITY > 0 else None
+
+    def call_args(bufs):
+        _, keys_a, vals_a, keys_s, vals_s, sort_ws, ws_bytes = bufs
+        b = _lib.BinSortArgs(N, W, H, 0, ptr(st.geom), ptr(st.point_offsets), ptr(keys_a), ptr(vals_a), ptr(keys_s),
+                             ptr(vals_s), ptr(st.ranges), ptr(sort_ws), ws_bytes, 0, 0, ptr(st.tile_order))
+        c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(vals_s), ptr(st.geom), ptr(bg), ptr(st.color), ptr(st.depth),
+                              ptr(st.final_T), ptr(st.n_contrib), ptr(st.tile_order))
+        return b, c
+    # ... and so are the argument blocks of the two calls that follow the wait: the GPU is idle until they are made
+    b, c = call_args(bufs) if bufs is not None else (None, None)
     # the data-dependent list length R: one small device->host read (stream sync)
     dmin, dmax, R = ((int(v) & 0xffffffff for v in scan_ws[:3].tolist()) if N > 0 else (0, 0, 0))
     st.num_rendered = R
@@ -109,17 +119,14 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     LAST_NUM_RENDERED = R
     if bufs is None or R > bufs[0]:
         bufs = list_buffers(_list_capacity(max(R, 1)))
-    _, keys_a, vals_a, st.keys_sorted, st.vals_sorted, sort_ws, ws_bytes = bufs
-    b = _lib.BinSortArgs(N, W, H, R, ptr(st.geom), ptr(st.point_offsets), ptr(keys_a), ptr(vals_a),
-                         ptr(st.keys_sorted), ptr(st.vals_sorted), ptr(st.ranges), ptr(sort_ws), ws_bytes, dmin, dmax,
-                         ptr(st.tile_order))
+        b, c = call_args(bufs)
+    st.keys_sorted, st.vals_sorted = bufs[3], bufs[4]
+    b.num_rendered, b.depth_bits_min, b.depth_bits_max = R, dmin, dmax
+    if R == 0:          # no list entries: the list pointer is NULL (the library then also accepts the NULL geom of an empty scene)
+        c.point_list = None
     _lib.call("fdgs_raster_bin_sort", b)
     if not keep_keys:
         st.keys_sorted = None
-
-    # no list entries: the list pointer is NULL (the library then also accepts the NULL geom of an empty scene)
-    c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted) if R > 0 else None, ptr(st.geom), ptr(bg), ptr(st.color),
-                          ptr(st.depth), ptr(st.final_T), ptr(st.n_contrib), ptr(st.tile_order))
     _lib.call("fdgs_raster_blend_fwd", c)
     return st
 
