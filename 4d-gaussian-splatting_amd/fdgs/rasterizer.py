@@ -87,6 +87,15 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
                                ptr(shs), ptr(colors_precomp), ptr(cov3D_precomp), ptr(st.geom), ptr(st.radii), ptr(st.tiles_touched), ptr(st.point_offsets),
                                ptr(scan_ws), int(activations))
     _lib.call("fdgs_raster_preprocess_fwd", a)
+    # the data-dependent list length R: one 12-byte device->host read into pinned memory, requested here and waited
+    # for on an event below (a synchronous copy of a device tensor goes through a staging buffer and a full stream
+    # synchronisation)
+    ready = None
+    if N > 0:
+        r_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+        r_host.copy_(scan_ws[:3], non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
 
     # everything whose size is known is allocated while the preprocess kernels run, before the host waits
     st.color = torch.empty(3, H, W, device=dev, dtype=torch.float32)
@@ -112,8 +121,11 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
         return b, c
     # ... and so are the argument blocks of the two calls that follow the wait: the GPU is idle until they are made
     b, c = call_args(bufs) if bufs is not None else (None, None)
-    # the data-dependent list length R: one small device->host read (stream sync)
-    dmin, dmax, R = ((int(v) & 0xffffffff for v in scan_ws[:3].tolist()) if N > 0 else (0, 0, 0))
+    if ready is not None:
+        ready.synchronize()
+        dmin, dmax, R = (int(v) & 0xffffffff for v in r_host.tolist())
+    else:
+        dmin, dmax, R = 0, 0, 0
     st.num_rendered = R
     global LAST_NUM_RENDERED
     LAST_NUM_RENDERED = R
