@@ -201,16 +201,33 @@ def _fill_params(net, grads=None):
 RESIDUAL_GRAD_HOOK = None
 
 
+class SplitSH:
+    """The SH coefficients as the two tensors GaussianModel keeps (src/model/gaussian_model.py:64-65, _features_dc
+    [N,1,3] and _features_rest [N,15,3]) in place of their concatenation get_features (:86-89): accepted as `shs` by
+    DeformationFields.forward under torch.no_grad(), where the [N,16,3] copy (58 MB at 300k Gaussians, per frame)
+    would only be read once by the deformation kernel."""
+    __slots__ = ("dc", "rest")
+
+    def __init__(self, dc, rest):
+        self.dc, self.rest = dc, rest
+
+
 class _DeformFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, grad_mode, xyz, scales, rotations, opacity, shs, time, *params):
-        _lib.require_gpu(xyz, scales, rotations, opacity, shs, *params)
+        sh_rest = None
+        if isinstance(shs, SplitSH):
+            if grad_mode:
+                raise ValueError("SplitSH is an inference input: pass get_features where gradients are needed")
+            shs, sh_rest = shs.dc, shs.rest
+        _lib.require_gpu(xyz, scales, rotations, opacity, shs, sh_rest, *params)
         N = xyz.shape[0]
         dev = xyz.device
         def c(t):
             t = t.detach()
             return t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
         xyz_c, sc_c, ro_c, op_c, sh_c = c(xyz), c(scales), c(rotations), c(opacity), c(shs)
+        rest_c = c(sh_rest) if sh_rest is not None else None
         time_scalar = 0.0
         if isinstance(time, (float, int)):
             time_scalar, time_c = float(time), None
@@ -218,7 +235,9 @@ class _DeformFunction(torch.autograd.Function):
             time_c = c(time).reshape(-1)
             if time_c.numel() != N:
                 raise ValueError("time must have one entry per point")
-        outs = [torch.empty_like(t) for t in (xyz_c, sc_c, ro_c, op_c, sh_c)]
+        outs = [torch.empty_like(t) for t in (xyz_c, sc_c, ro_c, op_c)]
+        outs.append(torch.empty_like(sh_c) if rest_c is None else
+                    torch.empty(N, 1 + rest_c.shape[1], 3, device=dev, dtype=torch.float32))
         # needs_input_grad is also set under torch.no_grad(); the caller's grad mode decides whether
         # the activations are saved (0.92 GB at 300k points)
         need_grad = grad_mode and any(ctx.needs_input_grad)
@@ -236,7 +255,7 @@ class _DeformFunction(torch.autograd.Function):
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), time_scalar,
                                ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), ptr(outs[4]), ptr(hidden),
-                               ptr(act), ptr(mask), ptr(yhid), ptr(yfeat), ptr(ws), ws_bytes)
+                               ptr(act), ptr(mask), ptr(yhid), ptr(yfeat), ptr(ws), ws_bytes, ptr(rest_c))
         _lib.call("fdgs_deform_fwd", a)
         ctx.net = net
         ctx.time_scalar = time_scalar

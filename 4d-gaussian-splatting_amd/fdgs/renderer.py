@@ -17,6 +17,7 @@ import math
 import torch
 
 from . import _lib
+from . import deformation as _deformation
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
@@ -47,7 +48,15 @@ def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifi
 
     means2D = screenspace_points
     opacity = pc._opacity
-    shs = pc.get_features
+    # Without gradients, with this package's deformation field and a model that keeps the SH coefficients as the
+    # reference's GaussianModel does, the two tensors go to the deformation kernel as they are: get_features is a
+    # concatenation into a fresh [N,16,3] tensor on every call (gaussian_model.py:86-89)
+    split_sh = ("fine" in stage and not torch.is_grad_enabled() and override_color is None and not convert_SHs_python
+                and isinstance(getattr(deforms, "deformation_fields", None), _deformation.DeformationFields)
+                and isinstance(getattr(pc, "_features_dc", None), torch.Tensor)
+                and isinstance(getattr(pc, "_features_rest", None), torch.Tensor)
+                and pc._features_dc.dim() == 3 and pc._features_dc.shape[1] == 1 and pc._features_rest.shape[1] == 15)
+    shs = _deformation.SplitSH(pc._features_dc, pc._features_rest) if split_sh else pc.get_features
     scales = None
     rotations = None
     cov3D_precomp = None

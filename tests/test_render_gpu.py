@@ -240,3 +240,34 @@ def test_render_sequence_gives_the_frames_of_the_host_loop():
             x = render(cam, g, deforms, bg)["render"]
             ref = (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8).transpose(1, 2, 0)
             assert np.array_equal(img, ref)
+
+
+def test_no_grad_render_without_the_sh_concatenation():
+    """Under torch.no_grad() render() hands _features_dc / _features_rest to the deformation kernel as they are; the
+    image is the one of the route through get_features, bit for bit."""
+    from fdgs import deformation, scene_synth as ss
+    from fdgs.deformation import DeformationFields
+    from fdgs.renderer import render
+    from fdgs.train_step import DeformHolder
+    dev = torch.device("cuda:0")
+    g = ss.GaussianParams(5000, device=dev, scale_mult=3.0)
+    torch.manual_seed(3)
+    net = DeformationFields(ss.DYNERF_NET_KWARGS)
+    ss.perturb_deformation_(net)
+    net = net.to(dev)
+    deforms = DeformHolder(net)
+    cam = ss.make_cameras(3, 128, 96, device=dev)[1]
+    bg = torch.ones(3, device=dev)
+    with torch.no_grad():
+        a = render(cam, g, deforms, bg)
+        n = g._xyz.shape[0]
+        outs = net(g._xyz, g._scaling, g._rotation, g._opacity, deformation.SplitSH(g._features_dc, g._features_rest),
+                   float(cam.time))
+        ref = net(g._xyz, g._scaling, g._rotation, g._opacity, g.get_features, float(cam.time))
+    for x, y in zip(outs, ref):
+        assert x.shape == y.shape and torch.equal(x, y)
+    b = render(cam, g, deforms, bg)          # with gradients: the concatenated tensor
+    assert torch.equal(a["render"], b["render"].detach()) and torch.equal(a["radii"], b["radii"])
+    with pytest.raises(ValueError):
+        net(g._xyz, g._scaling, g._rotation, g._opacity, deformation.SplitSH(g._features_dc, g._features_rest),
+            float(cam.time))
