@@ -59,40 +59,45 @@ class FrameSink:
         return [self.host[i].numpy() for i in range(self.count)]
 
 
-def render_sequence(views, pc, deforms, bg_color, keep_renders=False, streams=1, **render_kwargs):
-    """The loop of render.py:74-79 over `views`: returns (render_images, render_list) - the uint8 [H,W,3] frames and,
-    with keep_renders, the float renders the reference also keeps for writing the PNGs.
+def render_sequence(views, pc, deforms, bg_color, keep_renders=False, to8b=True, pipelined=True, **render_kwargs):
+    """The loop of render.py:74-79 over `views`: returns (render_images, render_list) - the uint8 [H,W,3] frames
+    (to8b) and, with keep_renders, the float renders the reference also keeps for writing the PNGs.
 
-    Frames are independent, and each one makes the host wait once (the length of its tile lists comes back from the
-    device before the sort can be enqueued).  With `streams` > 1 consecutive frames alternate between that many
-    streams, so that the GPU has another frame's work queued during the round trip; measured at 1352 x 1014 with
-    300k Gaussians this is within the run-to-run spread of one stream (1450-1520 frames per second either way: the
-    round trip is about 0.05 of a frame's 0.65 ms), so one stream is the default."""
-    from .renderer import render
+    Every frame makes the host wait once: the length of its tile lists comes back from the device before the sort
+    can be enqueued, and the GPU has nothing to do from the end of the preprocess kernels until the host has woken
+    up and launched the sort (about 0.06 of a frame's 0.63 ms at 1352 x 1014 with 300k Gaussians).  Frames are
+    independent, so with `pipelined` the NEXT frame's deformation field and preprocess are enqueued before the host
+    waits for the current frame's length: the GPU works on them through the round trip.  The frames are the same
+    (same kernels on the same inputs, tests/test_render_gpu.py); two frames' intermediates are alive at a time."""
+    from .renderer import prepare, render
+    from .rasterizer import rasterize_begin_call, rasterize_finish
     views = list(views)
     if not views:
         return [], []
     sink = None
     render_list = []
-    dev = None
-    lanes = None
+
+    def take(rendering):
+        nonlocal sink
+        if to8b:
+            if sink is None:
+                sink = FrameSink(len(views), rendering.shape[1], rendering.shape[2], rendering.shape[0],
+                                 device=rendering.device)
+            sink.push(rendering)
+        if keep_renders:
+            render_list.append(rendering)
+
     with torch.no_grad():
-        for i, view in enumerate(views):
-            if lanes is None:
-                dev = torch.device(bg_color.device if isinstance(bg_color, torch.Tensor) else "cuda:0")
-                caller = torch.cuda.current_stream(dev)
-                lanes = [torch.cuda.Stream(dev) for _ in range(max(1, int(streams)))] if streams > 1 else [caller]
-                for s in lanes:
-                    s.wait_stream(caller)           # the parameters may still be in flight on the caller's stream
-            with torch.cuda.stream(lanes[i % len(lanes)]):
-                rendering = render(view, pc, deforms, bg_color, **render_kwargs)["render"]
-                if sink is None:
-                    sink = FrameSink(len(views), rendering.shape[1], rendering.shape[2], rendering.shape[0],
-                                     device=rendering.device)
-                sink.push(rendering)
-            if keep_renders:
-                render_list.append(rendering)
-    images = sink.frames()
-    for s in lanes:
-        s.synchronize()                             # the renders are the caller's to use on any stream
-    return images, render_list
+        if not pipelined:
+            for view in views:
+                take(render(view, pc, deforms, bg_color, **render_kwargs)["render"])
+        else:
+            def begin(view):
+                settings, kwargs, _ = prepare(view, pc, deforms, bg_color, **render_kwargs)
+                return rasterize_begin_call(settings, **kwargs)
+            pending = begin(views[0])
+            for i in range(len(views)):
+                following = begin(views[i + 1]) if i + 1 < len(views) else None
+                take(rasterize_finish(pending).color)
+                pending = following
+    return (sink.frames() if sink is not None else []), render_list

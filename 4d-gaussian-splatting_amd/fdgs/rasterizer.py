@@ -62,11 +62,17 @@ class RasterState:
                  "ranges", "tile_order", "final_T", "n_contrib", "color", "depth", "cam")
 
 
-def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=False, colors_precomp=None,
-                      cov3D_precomp=None, activations=0):
-    """Runs stages 1-6 through the C ABI and returns a RasterState.  Either shs or colors_precomp [N,3],
-    either (scales, rotations) or cov3D_precomp [N,6].  `activations` (ACT_* flags of fdgs._lib) marks
-    scales / rotations / opacities as raw parameters whose activation the preprocess kernel applies."""
+class _PendingRaster:
+    """A forward pass between its two halves: the preprocess call is enqueued and the list length requested."""
+    __slots__ = ("st", "ready", "r_host", "bufs", "args", "dims", "list_buffers", "call_args", "inputs")
+
+
+def rasterize_begin(means3D, shs, opacities, scales, rotations, S, colors_precomp=None, cov3D_precomp=None,
+                    activations=0):
+    """First half of rasterize_forward: stages 1-2 are enqueued, the list length is on its way to the host, every
+    buffer whose size is known is allocated; nothing waits.  rasterize_finish(pending) does the rest.  (A playback
+    loop enqueues the next frame's deformation and first half before it finishes the current frame, so the GPU has
+    work while the host waits for the length.)"""
     _lib.require_gpu(means3D, shs, opacities, scales, rotations, colors_precomp, cov3D_precomp, S.bg, S.viewmatrix,
                      S.projmatrix, S.campos)
     dev = means3D.device
@@ -87,15 +93,18 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
                                ptr(shs), ptr(colors_precomp), ptr(cov3D_precomp), ptr(st.geom), ptr(st.radii), ptr(st.tiles_touched), ptr(st.point_offsets),
                                ptr(scan_ws), int(activations))
     _lib.call("fdgs_raster_preprocess_fwd", a)
+    p = _PendingRaster()
+    p.st = st
+    p.inputs = (means3D, shs, opacities, scales, rotations, colors_precomp, cov3D_precomp, scan_ws)   # alive until finish
     # the data-dependent list length R: one 12-byte device->host read into pinned memory, requested here and waited
-    # for on an event below (a synchronous copy of a device tensor goes through a staging buffer and a full stream
-    # synchronisation)
-    ready = None
+    # for on an event in the second half (a synchronous copy of a device tensor goes through a staging buffer and a
+    # full stream synchronisation)
+    p.ready = p.r_host = None
     if N > 0:
-        r_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
-        r_host.copy_(scan_ws[:3], non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record()
+        p.r_host = torch.empty(3, dtype=torch.int32, pin_memory=True)
+        p.r_host.copy_(scan_ws[:3], non_blocking=True)
+        p.ready = torch.cuda.Event()
+        p.ready.record()
 
     # everything whose size is known is allocated while the preprocess kernels run, before the host waits
     st.color = torch.empty(3, H, W, device=dev, dtype=torch.float32)
@@ -104,13 +113,12 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     st.n_contrib = torch.empty(H, W, device=dev, dtype=torch.int32)
     st.ranges = torch.empty(gx * gy, 2, device=dev, dtype=torch.int32)
     st.tile_order = torch.empty(gx * gy, device=dev, dtype=torch.int32)     # tiles by decreasing list length
-    # ... the R-sized ones too, at the capacity of the previous calls (redone below in the rare case R outgrew it)
+    # ... the R-sized ones too, at the capacity of the previous calls (redone in the rare case R outgrew it)
     def list_buffers(cap):
         ws_bytes = lib.fdgs_raster_sort_workspace_bytes(cap)
         return (cap, torch.empty(cap, device=dev, dtype=torch.int64), torch.empty(cap, device=dev, dtype=torch.int32),
                 torch.empty(cap, device=dev, dtype=torch.int64), torch.empty(cap, device=dev, dtype=torch.int32),
                 torch.empty(ws_bytes, device=dev, dtype=torch.uint8), ws_bytes)
-    bufs = list_buffers(_LIST_CAPACITY) if _LIST_CAPACITY > 0 else None
 
     def call_args(bufs):
         _, keys_a, vals_a, keys_s, vals_s, sort_ws, ws_bytes = bufs
@@ -119,19 +127,38 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
         c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(vals_s), ptr(st.geom), ptr(bg), ptr(st.color), ptr(st.depth),
                               ptr(st.final_T), ptr(st.n_contrib), ptr(st.tile_order))
         return b, c
+    p.list_buffers, p.call_args = list_buffers, call_args
+    p.bufs = list_buffers(_LIST_CAPACITY) if _LIST_CAPACITY > 0 else None
     # ... and so are the argument blocks of the two calls that follow the wait: the GPU is idle until they are made
-    b, c = call_args(bufs) if bufs is not None else (None, None)
-    if ready is not None:
-        ready.synchronize()
-        dmin, dmax, R = (int(v) & 0xffffffff for v in r_host.tolist())
+    p.args = call_args(p.bufs) if p.bufs is not None else (None, None)
+    return p
+
+
+def rasterize_begin_call(S, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                         cov3D_precomp=None, activations=0):
+    """rasterize_begin with the keyword arguments of GaussianRasterizer.forward (no gradients): the inputs are
+    brought to contiguous float32 as the autograd route does."""
+    opt = lambda t: None if t is None else _f32c(t)
+    return rasterize_begin(_f32c(means3D), opt(shs), _f32c(opacities).reshape(-1), opt(scales), opt(rotations), S,
+                           colors_precomp=opt(colors_precomp), cov3D_precomp=opt(cov3D_precomp),
+                           activations=int(activations))
+
+
+def rasterize_finish(p, keep_keys=False):
+    """Second half: waits for the list length, then stages 3-6.  Returns the RasterState."""
+    st, bufs = p.st, p.bufs
+    b, c = p.args
+    if p.ready is not None:
+        p.ready.synchronize()
+        dmin, dmax, R = (int(v) & 0xffffffff for v in p.r_host.tolist())
     else:
         dmin, dmax, R = 0, 0, 0
     st.num_rendered = R
     global LAST_NUM_RENDERED
     LAST_NUM_RENDERED = R
     if bufs is None or R > bufs[0]:
-        bufs = list_buffers(_list_capacity(max(R, 1)))
-        b, c = call_args(bufs)
+        bufs = p.list_buffers(_list_capacity(max(R, 1)))
+        b, c = p.call_args(bufs)
     st.keys_sorted, st.vals_sorted = bufs[3], bufs[4]
     b.num_rendered, b.depth_bits_min, b.depth_bits_max = R, dmin, dmax
     if R == 0:          # no list entries: the list pointer is NULL (the library then also accepts the NULL geom of an empty scene)
@@ -140,7 +167,17 @@ def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=F
     if not keep_keys:
         st.keys_sorted = None
     _lib.call("fdgs_raster_blend_fwd", c)
+    p.inputs = p.bufs = p.args = p.list_buffers = p.call_args = None
     return st
+
+
+def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=False, colors_precomp=None,
+                      cov3D_precomp=None, activations=0):
+    """Runs stages 1-6 through the C ABI and returns a RasterState.  Either shs or colors_precomp [N,3],
+    either (scales, rotations) or cov3D_precomp [N,6].  `activations` (ACT_* flags of fdgs._lib) marks
+    scales / rotations / opacities as raw parameters whose activation the preprocess kernel applies."""
+    return rasterize_finish(rasterize_begin(means3D, shs, opacities, scales, rotations, S, colors_precomp=colors_precomp,
+                                            cov3D_precomp=cov3D_precomp, activations=activations), keep_keys=keep_keys)
 
 
 def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, colors_precomp=None, cov3D_precomp=None,

@@ -21,8 +21,11 @@ from . import deformation as _deformation
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
-def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-           stage="fine", cam_type=None, debug=False, convert_SHs_python=False, compute_cov3D_python=False):
+def prepare(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+            stage="fine", cam_type=None, debug=False, convert_SHs_python=False, compute_cov3D_python=False):
+    """Everything render() does before it calls the rasterizer (gaussian_renderer/__init__.py:21-102): the settings
+    tuple, the deformation field, the activations.  Returns (raster_settings, the rasterizer's keyword arguments,
+    the gradient carrier of the 2-D means)."""
     means3D = pc.get_xyz
     dev = means3D.device
     # gradient carrier for the 2-D means (gaussian_renderer/__init__.py:27-31)
@@ -44,7 +47,6 @@ def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifi
     else:
         raster_settings = viewpoint_camera["camera"]
         time_value = viewpoint_camera["time"]
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     means2D = screenspace_points
     opacity = pc._opacity
@@ -113,9 +115,18 @@ def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifi
         colors_precomp = override_color
         shs_final = None
 
-    rendered_image, radii, depth = rasterizer(
-        means3D=means3D_final, means2D=means2D, shs=shs_final, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales_final, rotations=rotations_final, cov3D_precomp=cov3D_precomp, activations=activations)
+    return raster_settings, dict(means3D=means3D_final, means2D=means2D, shs=shs_final, colors_precomp=colors_precomp,
+                                 opacities=opacity, scales=scales_final, rotations=rotations_final,
+                                 cov3D_precomp=cov3D_precomp, activations=activations), screenspace_points
+
+
+def render(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+           stage="fine", cam_type=None, debug=False, convert_SHs_python=False, compute_cov3D_python=False):
+    raster_settings, kwargs, screenspace_points = prepare(
+        viewpoint_camera, pc, deforms, bg_color, scaling_modifier=scaling_modifier, override_color=override_color,
+        stage=stage, cam_type=cam_type, debug=debug, convert_SHs_python=convert_SHs_python,
+        compute_cov3D_python=compute_cov3D_python)
+    rendered_image, radii, depth = GaussianRasterizer(raster_settings=raster_settings)(**kwargs)
     return {"render": rendered_image,
             "viewspace_points": screenspace_points,
             "visibility_filter": radii > 0,

@@ -411,7 +411,7 @@ def main():
         batch8 = args.batch8_steps / (time.perf_counter() - t3)
 
     # inference-only legs: deformation + forward rasterizer, frames strided over ranks, no collective
-    fps = fps_d2h = fps_d2h_host = None
+    fps = fps_d2h = fps_d2h_host = fps_pipelined = None
     if args.render_frames > 0:
         import numpy as np
         frames = list(range(rank, args.render_frames, world))
@@ -443,6 +443,13 @@ def main():
             sync()
             fps_d2h = args.render_frames / max_over_ranks(time.perf_counter() - t1)
             del images
+            # the same loop without the 8-bit frames: what the pipelining of consecutive frames is worth by itself
+            # (render_fps above is the plain loop of render() calls, one host wait per frame with an idle GPU)
+            sync()
+            t1 = time.perf_counter()
+            render_sequence(views, g, deforms, bg, to8b=False)
+            sync()
+            fps_pipelined = args.render_frames / max_over_ranks(time.perf_counter() - t1)
 
             def to8b(x):
                 return (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8)
@@ -536,6 +543,7 @@ def main():
             "train_it_s_same_batch_one_gpu": one_gpu,
             "speedup_over_one_gpu": (args.steps / elapsed / one_gpu) if one_gpu else None,
             "render_fps": fps,
+            "render_fps_pipelined": fps_pipelined,
             "render_fps_with_d2h": fps_d2h,
             "render_fps_with_d2h_host_conversion": fps_d2h_host,
             "kernel_ms": per_call,

@@ -216,8 +216,10 @@ def test_frames_to8b_match_numpy():
         sink.push(frames[0].to(dev))
 
 
-def test_render_sequence_gives_the_frames_of_the_host_loop():
-    """render_sequence (render.py:74-79) against render() + the host conversion, frame by frame."""
+@pytest.mark.parametrize("pipelined", [True, False])
+def test_render_sequence_gives_the_frames_of_the_host_loop(pipelined):
+    """render_sequence (render.py:74-79) against render() + the host conversion, frame by frame; `pipelined`: the next
+    frame's deformation and preprocess are enqueued before the current frame's list length is waited for."""
     import numpy as np
     from fdgs import scene_synth as ss
     from fdgs.deformation import DeformationFields
@@ -231,13 +233,16 @@ def test_render_sequence_gives_the_frames_of_the_host_loop():
     ss.perturb_deformation_(net)
     net = net.to(dev)
     deforms = DeformHolder(net)
-    cams = ss.make_cameras(4, 96, 64, device=dev)
+    cams = ss.make_cameras(5, 96, 64, device=dev)
     bg = torch.ones(3, device=dev)
-    images, renders = render_sequence(cams, g, deforms, bg, keep_renders=True)
+    images, renders = render_sequence(cams, g, deforms, bg, keep_renders=True, pipelined=pipelined)
     assert len(images) == len(cams) == len(renders)
+    only_renders = render_sequence(cams[:2], g, deforms, bg, keep_renders=True, to8b=False, pipelined=pipelined)
+    assert only_renders[0] == [] and torch.equal(only_renders[1][1], renders[1])
     with torch.no_grad():
-        for cam, img in zip(cams, images):
+        for cam, img, kept in zip(cams, images, renders):
             x = render(cam, g, deforms, bg)["render"]
+            assert torch.equal(x, kept)
             ref = (255 * np.clip(x.cpu().numpy(), 0, 1)).astype(np.uint8).transpose(1, 2, 0)
             assert np.array_equal(img, ref)
 
