@@ -535,9 +535,23 @@ extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
     if (!a || a->num_points < 0 || a->num_rendered < 0 || a->image_width <= 0 || a->image_height <= 0)
         return FDGS_EINVAL;
     if (a->num_rendered > 0x7fffffffLL) return FDGS_EINVAL;
+    if (a->phase < FDGS_BINSORT_ALL || a->phase > FDGS_BINSORT_FINISH) return FDGS_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int gx = fdgs_tiles_x(a->image_width), gy = fdgs_tiles_y(a->image_height);
     const int tiles = gx * gy;
+    // FDGS_SORT=radix: the least-significant-digit radix sort over all R keys; otherwise the tile-binned sort
+    // (tile_sort.h) wherever it applies.  Both give the same keys, values and ranges.
+    const char* sort_env = getenv("FDGS_SORT");
+    const bool binned = !(sort_env && sort_env[0] == 'r');
+    if (a->phase == FDGS_BINSORT_COUNT) {           // before the list length is known: the per-tile counts
+        if (a->num_points == 0 || !binned) return FDGS_OK;
+        if (!a->geom || !a->point_offsets || !a->sort_workspace) return FDGS_EINVAL;
+        if (a->sort_workspace_bytes < fdgs_raster_sort_workspace_bytes(0)) return FDGS_EWORKSPACE;
+        const int rc = fdgs_tile_sort(a, (uint32_t*)a->sort_workspace + FDGS_RADIX_WS_WORDS,
+                                      a->sort_workspace_bytes / sizeof(uint32_t) - FDGS_RADIX_WS_WORDS, s,
+                                      FDGS_BINSORT_COUNT);
+        return rc == 1 ? FDGS_OK : rc;
+    }
     if (!a->ranges) return FDGS_EINVAL;
     const int64_t R = a->num_rendered;
     if (R == 0 || a->num_points == 0) {
@@ -552,12 +566,9 @@ extern "C" int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream) {
         !a->vals_sorted || !a->sort_workspace)
         return FDGS_EINVAL;
     if (a->sort_workspace_bytes < fdgs_raster_sort_workspace_bytes(R)) return FDGS_EWORKSPACE;
-    // FDGS_SORT=radix: the least-significant-digit radix sort over all R keys; otherwise the tile-binned sort
-    // (tile_sort.h) wherever it applies.  Both give the same keys, values and ranges.
-    const char* sort_env = getenv("FDGS_SORT");
-    if (!(sort_env && sort_env[0] == 'r')) {
+    if (binned) {
         const int rc = fdgs_tile_sort(a, (uint32_t*)a->sort_workspace + FDGS_RADIX_WS_WORDS,
-                                      a->sort_workspace_bytes / sizeof(uint32_t) - FDGS_RADIX_WS_WORDS, s);
+                                      a->sort_workspace_bytes / sizeof(uint32_t) - FDGS_RADIX_WS_WORDS, s, a->phase);
         if (rc != 1) return rc;
     }
     int tile_bits = 0;

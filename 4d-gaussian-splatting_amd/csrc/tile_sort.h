@@ -614,7 +614,7 @@ static_assert(TS_CAP_TAIL <= (1 << (3 * TS_TRIPLES)), "bit triples of the LDS so
 
 // Returns FDGS_OK or an error, or 1 when this path does not apply (more tiles than the LDS histogram holds,
 // workspace too small): the caller then runs the radix sort.
-int fdgs_tile_sort(const fdgs_binsort_args* a, uint32_t* ws, size_t ws_words, hipStream_t s) {
+int fdgs_tile_sort(const fdgs_binsort_args* a, uint32_t* ws, size_t ws_words, hipStream_t s, int phase) {
     const int gx = fdgs_tiles_x(a->image_width), gy = fdgs_tiles_y(a->image_height);
     const int tiles = gx * gy;
     ts_plan plan;
@@ -635,13 +635,16 @@ int fdgs_tile_sort(const fdgs_binsort_args* a, uint32_t* ws, size_t ws_words, hi
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)walk_lds) != hipSuccess)
             return FDGS_ELAUNCH;
     }
-    hipLaunchKernelGGL(tile_walk_kernel<false>, dim3(plan.groups), dim3(TS_WALK_THREADS), walk_lds, s, a->num_points,
-                       plan.per_group, a->geom, a->point_offsets, gx, gy, table, tile_start, binned, totals, order,
-                       a->ranges, desc);
-    FDGS_CHECK_LAUNCH();
-    hipLaunchKernelGGL(tile_table_scan_kernel, dim3((tiles + 31) / 32), dim3(TS_SCAN_THREADS), 0, s, table, totals,
-                       tiles, plan.groups);
-    FDGS_CHECK_LAUNCH();
+    if (phase != FDGS_BINSORT_FINISH) {             // the counting part: needs neither the list length nor the list buffers
+        hipLaunchKernelGGL(tile_walk_kernel<false>, dim3(plan.groups), dim3(TS_WALK_THREADS), walk_lds, s,
+                           a->num_points, plan.per_group, a->geom, a->point_offsets, gx, gy, table, tile_start,
+                           binned, totals, order, a->ranges, desc);
+        FDGS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(tile_table_scan_kernel, dim3((tiles + 31) / 32), dim3(TS_SCAN_THREADS), 0, s, table,
+                           totals, tiles, plan.groups);
+        FDGS_CHECK_LAUNCH();
+        if (phase == FDGS_BINSORT_COUNT) return FDGS_OK;
+    }
     hipLaunchKernelGGL(tile_walk_kernel<true>, dim3(plan.groups + 1), dim3(TS_WALK_THREADS), walk_lds, s,
                        a->num_points, plan.per_group, a->geom, a->point_offsets, gx, gy, table, tile_start, binned,
                        totals, order, a->ranges, desc);

@@ -38,7 +38,7 @@ class BinSortArgs(C.Structure):
                 ("geom", c_p), ("point_offsets", c_p),
                 ("keys_unsorted", c_p), ("vals_unsorted", c_p), ("keys_sorted", c_p), ("vals_sorted", c_p),
                 ("ranges", c_p), ("sort_workspace", c_p), ("sort_workspace_bytes", c_sz),
-                ("depth_bits_min", C.c_uint32), ("depth_bits_max", C.c_uint32), ("tile_order", c_p)]
+                ("depth_bits_min", C.c_uint32), ("depth_bits_max", C.c_uint32), ("tile_order", c_p), ("phase", c_i32)]
 
 
 class BlendFwdArgs(C.Structure):
@@ -228,7 +228,9 @@ SYMBOLS = {
     "fdgs_deform_bwd": (C.c_int, [C.POINTER(DeformBwdArgs), c_p]),
 }
 
-ABI_VERSION = 23
+BINSORT_ALL, BINSORT_COUNT, BINSORT_FINISH = 0, 1, 2      # fdgs_binsort_args.phase
+
+ABI_VERSION = 24
 
 
 def _load():

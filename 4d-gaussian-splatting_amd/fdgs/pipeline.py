@@ -241,6 +241,11 @@ class ViewPipeline:
                                       ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom),
                                       ptr(self.tile_order)))
         bs = binsort_args() if self.capacity > 0 else None
+        counted = False
+        if bs is not None:              # the counting part of the tile lists runs while the list length travels
+            bs.phase = _lib.BINSORT_COUNT
+            _lib.call("fdgs_raster_bin_sort", bs)
+            counted = True
         bf, bb = list_args() if self.capacity > 0 else (None, None)
         # the view's loss is this term alone: its gradient comes out of the same pass over the two images
         l1 = _lib.L1FwdArgs(n_img, ptr(self.color), ptr(gt), float(scale), ptr(loss_buf), ptr(self.l1_partial),
@@ -256,7 +261,9 @@ class ViewPipeline:
             self._list_buffers(max(R, 1), dev)
             bs = binsort_args()
             bf, bb = list_args()
+            counted = False             # another workspace: the counts are taken again
         bs.num_rendered, bs.depth_bits_min, bs.depth_bits_max = R, dmin, dmax
+        bs.phase = _lib.BINSORT_FINISH if counted else _lib.BINSORT_ALL
         if R == 0:
             bf.point_list = bb.point_list = None
         _lib.call("fdgs_raster_bin_sort", bs)

@@ -64,7 +64,7 @@ class RasterState:
 
 class _PendingRaster:
     """A forward pass between its two halves: the preprocess call is enqueued and the list length requested."""
-    __slots__ = ("st", "ready", "r_host", "bufs", "args", "dims", "list_buffers", "call_args", "inputs")
+    __slots__ = ("st", "ready", "r_host", "bufs", "args", "dims", "list_buffers", "call_args", "inputs", "counted")
 
 
 def rasterize_begin(means3D, shs, opacities, scales, rotations, S, colors_precomp=None, cov3D_precomp=None,
@@ -131,6 +131,12 @@ def rasterize_begin(means3D, shs, opacities, scales, rotations, S, colors_precom
     p.bufs = list_buffers(_LIST_CAPACITY) if _LIST_CAPACITY > 0 else None
     # ... and so are the argument blocks of the two calls that follow the wait: the GPU is idle until they are made
     p.args = call_args(p.bufs) if p.bufs is not None else (None, None)
+    # the counting part of the tile lists needs no list length: it runs while the length travels to the host
+    p.counted = False
+    if p.bufs is not None and N > 0:
+        p.args[0].phase = _lib.BINSORT_COUNT
+        _lib.call("fdgs_raster_bin_sort", p.args[0])
+        p.counted = True
     return p
 
 
@@ -156,11 +162,14 @@ def rasterize_finish(p, keep_keys=False):
     st.num_rendered = R
     global LAST_NUM_RENDERED
     LAST_NUM_RENDERED = R
+    counted = p.counted
     if bufs is None or R > bufs[0]:
         bufs = p.list_buffers(_list_capacity(max(R, 1)))
         b, c = p.call_args(bufs)
+        counted = False                 # another workspace: the counts are taken again
     st.keys_sorted, st.vals_sorted = bufs[3], bufs[4]
     b.num_rendered, b.depth_bits_min, b.depth_bits_max = R, dmin, dmax
+    b.phase = _lib.BINSORT_FINISH if counted else _lib.BINSORT_ALL
     if R == 0:          # no list entries: the list pointer is NULL (the library then also accepts the NULL geom of an empty scene)
         c.point_list = None
     _lib.call("fdgs_raster_bin_sort", b)

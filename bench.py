@@ -488,7 +488,10 @@ def main():
     if rank == 0:
         def avg_ms(name):
             ev = prof.get(name, [])
-            return sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+            # fdgs_raster_bin_sort is made in two parts per view (the counts before the wait for the list length,
+            # the rest after): the figure is the two together
+            views = len(prof.get("fdgs_raster_blend_fwd", [])) if name == "fdgs_raster_bin_sort" else len(ev)
+            return sum(s.elapsed_time(e) for s, e in ev) / max(views, 1)
         per_call = {k: round(avg_ms(k), 4) for k in prof}
         R = sum(rendered) / max(len(rendered), 1)
         px = args.width * args.height

@@ -129,7 +129,17 @@ typedef struct {
      * logarithmic scale of the lengths; the order among tiles of one class is not defined), for the tile_order
      * argument of the blend calls.  Always a permutation of 0 .. tiles-1, also when R is 0.                   */
     uint32_t* tile_order;
+    /* 0: the whole call.  The call can also be made in two parts around the caller's wait for num_rendered, so that
+     * the GPU has work during that round trip: FDGS_BINSORT_COUNT right behind fdgs_raster_preprocess_fwd counts the
+     * (Gaussian, tile) pairs per tile (it reads num_points, the image size, geom, point_offsets and the sort
+     * workspace only; num_rendered may still be unknown), FDGS_BINSORT_FINISH, with the complete arguments and the
+     * SAME sort workspace, does the rest.  Where the tile-binned sort does not apply (radix sort selected or more than
+     * 32,768 tiles) the first part does nothing and the second everything.                                        */
+    int32_t phase;
 } fdgs_binsort_args;
+#define FDGS_BINSORT_ALL 0
+#define FDGS_BINSORT_COUNT 1
+#define FDGS_BINSORT_FINISH 2
 
 size_t fdgs_raster_sort_workspace_bytes(int64_t num_rendered);
 int fdgs_raster_bin_sort(const fdgs_binsort_args* a, void* stream);

@@ -128,6 +128,17 @@ def test_tile_binned_sort_long_lists_and_equal_depths(n, w, h, scale_mult, tied,
     assert torch.equal(vs.cpu(), svals)
     assert torch.equal(rg.cpu(), ranges)
     assert torch.equal(torch.sort(order.cpu().long())[0], torch.arange(gx * gy))
+    # the same call in its two parts (the counts before the list length is known, the rest after)
+    ks2, vs2, rg2 = torch.zeros_like(ks), torch.zeros_like(vs), torch.empty_like(rg)
+    ws2 = torch.empty_like(ws)
+    first = _lib.BinSortArgs(n, w, h, 0, ptr(st.geom), ptr(st.point_offsets), None, None, None, None, None, ptr(ws2),
+                             ws_bytes, 0, 0, None, _lib.BINSORT_COUNT)
+    _lib.call("fdgs_raster_bin_sort", first)
+    _lib.call("fdgs_raster_bin_sort", _lib.BinSortArgs(n, w, h, R, ptr(st.geom), ptr(st.point_offsets), ptr(ka), ptr(va),
+                                                       ptr(ks2), ptr(vs2), ptr(rg2), ptr(ws2), ws_bytes, 0, 0,
+                                                       ptr(order), _lib.BINSORT_FINISH))
+    torch.cuda.synchronize()
+    assert torch.equal(ks2, ks) and torch.equal(vs2, vs) and torch.equal(rg2, rg)
 
 
 def test_scan_in_two_launches_gives_the_same_lists(monkeypatch):
