@@ -10,9 +10,13 @@
 //                               is an LDS atomic on the workgroup's cursor of that tile, and
 //                               (depth bits << 32 | Gaussian id) goes to binned[slot].  One more workgroup orders the
 //                               tile ids by decreasing list length meanwhile.
-//   4. tile_sort_kernel         one workgroup per tile sorts the segment in LDS and writes the sorted keys
-//                               (tile << 32 | depth bits) and values (id); a second launch of a few large workgroups
-//                               takes the segments that are too long for the first
+//   4. tile_sort_kernel         one wave per tile (workgroups of several waves where the lists are long) sorts the
+//                               segment in LDS and writes the sorted keys (tile << 32 | depth bits) and values (id); a
+//                               second launch of a few large workgroups takes the segments that are too long for
+//                               the first
+//
+// Steps 1 and 2 need neither the list length R nor the R-sized buffers: a caller may run them (phase
+// FDGS_BINSORT_COUNT) while R is on its way to the host and the rest afterwards (FDGS_BINSORT_FINISH).
 //
 // The result is the one the stable radix sort gives: duplicateWithKeys emits the pairs in Gaussian order, so among
 // equal (tile, depth) keys the stable sort leaves the ids ascending - which is the order of the 64-bit numbers
