@@ -141,6 +141,64 @@ def test_tile_binned_sort_long_lists_and_equal_depths(n, w, h, scale_mult, tied,
     assert torch.equal(ks2, ks) and torch.equal(vs2, vs) and torch.equal(rg2, rg)
 
 
+def test_tile_lists_of_random_scenes_match_the_radix_sort(monkeypatch):
+    """Seeded random scenes (image sizes that are not multiples of the tile, 1 to 150,000 Gaussians, splat sizes from
+    a fraction of a tile to most of the image, a third of the Gaussians at one position in some): the tile-binned
+    lists, ranges and launch order against the radix sort's on the same preprocess outputs, bit for bit.  The radix
+    sort itself is held to the oracle by the tests above; the binned call is made on its own and its outputs are only
+    compared."""
+    import math
+    import random
+    from fdgs import rasterizer as fr, scene_synth as ss, _lib
+    from fdgs._lib import lib, ptr
+    dev = torch.device("cuda:0")
+    rng = random.Random(20240607)
+    nonempty = 0
+    for it in range(24):
+        w = rng.choice([16, 17, 64, 100, 257, 640, 1352, 1920])
+        h = rng.choice([16, 31, 48, 128, 360, 1014])
+        n = rng.choice([1, 2, 63, 64, 65, 500, 1023, 1024, 1025, 5000, 40000, 150000])
+        sm = rng.choice([0.3, 1.0, 3.0, 8.0, 20.0])
+        if n * sm > 400000:
+            sm = 1.0
+        tied = rng.choice([0, 0, n // 3])
+        cam = ss.make_cameras(5, w, h)[rng.randrange(5)]
+        g = ss.GaussianParams(n, seed=it + 7, scale_mult=sm, requires_grad=False)
+        xyz = g._xyz.clone()
+        if tied > 1:
+            xyz[:tied] = xyz[0]
+        S = _to_dev(rr.Settings(h, w, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.ones(3), 1.0,
+                                cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center), dev)
+        monkeypatch.setenv("FDGS_SORT", "radix")
+        st = fr.rasterize_forward(xyz.to(dev), g.get_features.contiguous().to(dev),
+                                  torch.sigmoid(g._opacity).reshape(-1).to(dev), torch.exp(g._scaling).to(dev),
+                                  torch.nn.functional.normalize(g._rotation).to(dev), S, keep_keys=True)
+        torch.cuda.synchronize()
+        R = st.num_rendered
+        if R == 0:
+            continue
+        nonempty += 1
+        monkeypatch.setenv("FDGS_SORT", "tiles")
+        ws_bytes = lib.fdgs_raster_sort_workspace_bytes(R)
+        ka = torch.empty(R, device=dev, dtype=torch.int64)
+        va = torch.empty(R, device=dev, dtype=torch.int32)
+        ks = torch.zeros(R, device=dev, dtype=torch.int64)
+        vs = torch.zeros(R, device=dev, dtype=torch.int32)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        rg = torch.empty_like(st.ranges)
+        order = torch.empty_like(st.tile_order)
+        _lib.call("fdgs_raster_bin_sort", _lib.BinSortArgs(n, w, h, R, ptr(st.geom), ptr(st.point_offsets), ptr(ka),
+                                                           ptr(va), ptr(ks), ptr(vs), ptr(rg), ptr(ws), ws_bytes, 0, 0,
+                                                           ptr(order)))
+        torch.cuda.synchronize()
+        what = f"scene {it}: {w}x{h}, {n} Gaussians, scale x{sm}, {tied} at one position, {R} entries"
+        assert torch.equal(ks, st.keys_sorted[:R]), what
+        assert torch.equal(vs, st.vals_sorted[:R]), what
+        assert torch.equal(rg, st.ranges), what
+        assert torch.equal(torch.sort(order.long())[0], torch.arange(rg.shape[0], device=dev)), what
+    assert nonempty >= 12
+
+
 def test_scan_in_two_launches_gives_the_same_lists(monkeypatch):
     """Beyond 8192 groups of 256 Gaussians the scan of the tile counts takes a second launch (a one-workgroup scan of
     the group sums); forced here at a size the oracle handles."""
