@@ -1144,7 +1144,8 @@ extern "C" size_t fdgs_deform_bwd_workspace_bytes(const fdgs_deform_params* p, i
 // The HexPlane scatter (atomics-bound) and the weight-gradient products (matrix-core / memory-bound) only
 // depend on pass 1, not on each other: when the caller lends a second stream and two events
 // (fdgs_deform_bwd_args.side_stream / fork_event / join_event) they are issued on two streams (fork after
-// pass 1, join before returning to the caller's stream order).  The library itself owns no stream and no event.
+// pass 1, join before returning to the caller's stream order; a first fork before pass 1 starts what needs none of
+// its results, fork_event being recorded a second time after it).  The library itself owns no stream and no event.
 struct SideStream { hipStream_t stream; hipEvent_t fork, join; };
 
 extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
@@ -1289,18 +1290,15 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         FDGS_CHECK_LAUNCH();
         return FDGS_OK;
     };
-    // pass 1b + dW0 + plane-gradient layout change: everything downstream of dfeat; runs on stream hs
-    auto hex_tail = [&](hipStream_t hs) -> int {
-        if (hipMemsetAsync(grads_cl, 0, pf * sizeof(float), hs) != hipSuccess) return FDGS_ELAUNCH;
-        // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
-        hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
-        hk.ws_df = ws_df; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
-        hk.ws_feat = (a->yfeat && a->p.matmul == FDGS_MATMUL_SPLIT_BF16) ? nullptr : ws_feat;
-        hk.lds_time = (a->time == nullptr) ? 1 : 0;
-        // brick path: float64 windows of all twelve planes in LDS; the coarsest brick grid whose windows fit
-        HexBrickK bk;
-        int brick_lds_doubles = 0;
-        bool bricks = false;
+    // The brick path of the HexPlane backward: float64 windows of all twelve planes in LDS, on the coarsest brick grid
+    // whose windows fit.  Decided before pass 1 because the binning of the points reads nothing but xyz and may run
+    // beside that pass.
+    hk.lds_time = (a->time == nullptr) ? 1 : 0;
+    HexBrickK bk;
+    BrickBinK bb;
+    int brick_lds_doubles = 0;
+    bool bricks = false;
+    {
         const char* mode = getenv("FDGS_HEX_BWD");
         if (!(mode && mode[0] == 'f')) {            // FDGS_HEX_BWD=flat keeps the one-atomic-per-corner kernel
             static const int cand[4][3] = {{8, 8, 8}, {8, 8, 16}, {8, 16, 16}, {16, 16, 16}};
@@ -1321,32 +1319,51 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
                 }
             }
         }
+    }
+    if (bricks) {
+        bb.n = n; bb.xyz = a->xyz; bb.aabb = a->p.aabb;
+        bb.perm = ws_brick;
+        bb.brick_of = reinterpret_cast<unsigned short*>(ws_brick + n);
+        bb.counts = ws_brick + n + (n + 1) / 2;
+        bb.cursor = bb.counts + BRICK_MAX;
+        bb.work_count = bb.cursor + BRICK_MAX;
+        bb.work = bb.work_count + 16;
+        for (int ax = 0; ax < 3; ++ax) bb.nb[ax] = bk.nb[ax];
+    }
+    bool binned = false;
+    auto brick_binning = [&](hipStream_t hs) -> int {
+        const int nbr = bk.nb[0] * bk.nb[1] * bk.nb[2];
+        if (hipMemsetAsync(bb.counts, 0, (size_t)nbr * sizeof(int), hs) != hipSuccess) return FDGS_ELAUNCH;
+        const int sort_blocks = (n + BRICK_SORT_PTS - 1) / BRICK_SORT_PTS;
+        hipLaunchKernelGGL(brick_hist_kernel, dim3(sort_blocks), dim3(256), 0, hs, bb);
+        FDGS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(brick_plan_kernel, dim3(1), dim3(1024), 0, hs, bb);
+        FDGS_CHECK_LAUNCH();
+        hipLaunchKernelGGL(brick_scatter_kernel, dim3(sort_blocks), dim3(256), 0, hs, bb);
+        FDGS_CHECK_LAUNCH();
+        binned = true;
+        return FDGS_OK;
+    };
+    // pass 1b + dW0 + plane-gradient layout change: everything downstream of dfeat; runs on stream hs
+    bool grads_cleared = false;
+    auto hex_tail = [&](hipStream_t hs) -> int {
+        if (!grads_cleared && hipMemsetAsync(grads_cl, 0, pf * sizeof(float), hs) != hipSuccess) return FDGS_ELAUNCH;
+        // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
+        hk.aabb = a->p.aabb; hk.xyz = a->xyz; hk.time = a->time; hk.time_scalar = a->time_scalar;
+        hk.ws_df = ws_df; hk.g_xyz = a->g_xyz; hk.d_xyz = a->d_xyz;
+        hk.ws_feat = (a->yfeat && a->p.matmul == FDGS_MATMUL_SPLIT_BF16) ? nullptr : ws_feat;
         if (bricks) {
-            BrickBinK bb;
-            bb.n = n; bb.xyz = a->xyz; bb.aabb = a->p.aabb;
-            bb.perm = ws_brick;
-            bb.brick_of = reinterpret_cast<unsigned short*>(ws_brick + n);
-            bb.counts = ws_brick + n + (n + 1) / 2;
-            bb.cursor = bb.counts + BRICK_MAX;
-            bb.work_count = bb.cursor + BRICK_MAX;
-            bb.work = bb.work_count + 16;
-            for (int ax = 0; ax < 3; ++ax) bb.nb[ax] = bk.nb[ax];
-            const int nbr = bk.nb[0] * bk.nb[1] * bk.nb[2];
-            if (hipMemsetAsync(bb.counts, 0, (size_t)nbr * sizeof(int), hs) != hipSuccess) return FDGS_ELAUNCH;
-            const int sort_blocks = (n + BRICK_SORT_PTS - 1) / BRICK_SORT_PTS;
-            hipLaunchKernelGGL(brick_hist_kernel, dim3(sort_blocks), dim3(256), 0, hs, bb);
-            FDGS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(brick_plan_kernel, dim3(1), dim3(1024), 0, hs, bb);
-            FDGS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(brick_scatter_kernel, dim3(sort_blocks), dim3(256), 0, hs, bb);
-            FDGS_CHECK_LAUNCH();
+            if (!binned) {
+                rc = brick_binning(hs);
+                if (rc != FDGS_OK) return rc;
+            }
             bk.h = hk; bk.perm = bb.perm; bk.work = bb.work; bk.work_count = bb.work_count;
             const size_t bytes = (size_t)brick_lds_doubles * sizeof(double);
             if (bytes > 64 * 1024 &&
                 hipFuncSetAttribute((const void*)hexplane_bwd_brick_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)bytes) != hipSuccess)
                 return FDGS_ELAUNCH;
-            int max_work = nbr + n / BRICK_CH + 1;          // <= brick_max_work(n)
+            int max_work = bk.nb[0] * bk.nb[1] * bk.nb[2] + n / BRICK_CH + 1;     // <= brick_max_work(n)
             if (max_work > n) max_work = n;
             hipLaunchKernelGGL(hexplane_bwd_brick_kernel, dim3(max_work), dim3(BRICK_THREADS), bytes, hs, bk, brick_lds_doubles);
             FDGS_CHECK_LAUNCH();
@@ -1423,6 +1440,30 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         float* first = with_dw0 ? w2_slabs - dw0_floats : w2_slabs;
         const size_t floats = (size_t)W2_SLABS * W2_SLAB_FLOATS + DW * DW + DW + (with_dw0 ? dw0_floats : 0);
         if (split && hipMemsetAsync(first, 0, floats * sizeof(float), s) != hipSuccess) return FDGS_ELAUNCH;
+    }
+    // What depends on nothing of pass 1 goes to the side stream first and runs beside that pass (whose one wave per
+    // SIMD leaves the last round of its launch partly idle): the binning of the points into bricks and the column
+    // sums of the cotangents (db2), over all points at once.  FDGS_NO_EARLY_SIDE keeps the single fork after pass 1.
+    const bool early_side = side && !getenv("FDGS_NO_EARLY_SIDE");
+    bool colsum_done = false;
+    if (early_side) {
+        if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess)
+            return FDGS_ELAUNCH;
+        if (hipMemsetAsync(grads_cl, 0, pf * sizeof(float), side->stream) != hipSuccess) return FDGS_ELAUNCH;
+        grads_cleared = true;
+        if (bricks) {
+            rc = brick_binning(side->stream);
+            if (rc != FDGS_OK) return rc;
+        }
+        if (split) {
+            ColSumK cs;
+            cs.n = n;
+            for (int h = 0; h < 5; ++h) { cs.X[h] = gs[h]; cs.ncols[h] = kdim[h]; cs.out[h] = a->dp.b2[h]; }
+            cs.slabs_base = w2_slabs + (size_t)W2_SLABS * 59 * DW; cs.slabs = W2_SLABS;
+            hipLaunchKernelGGL(colsum_kernel, dim3(1024, 5), dim3(256), 0, side->stream, cs);
+            FDGS_CHECK_LAUNCH();
+            colsum_done = true;
+        }
     }
     for (int c0 = 0; c0 < n; c0 += chunk_pts) {
         const int cn = (n - c0) < chunk_pts ? (n - c0) : chunk_pts;
@@ -1521,8 +1562,10 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             FDGS_CHECK_LAUNCH();
             hipLaunchKernelGGL(deform_wgrad2_split_kernel<2>, dim3((tiles + tpb - 1) / tpb), dim3(64), 0, s, w2k);
             FDGS_CHECK_LAUNCH();
-            hipLaunchKernelGGL(colsum_kernel, dim3(1024, 5), dim3(256), 0, s, cs);
-            FDGS_CHECK_LAUNCH();
+            if (!colsum_done) {
+                hipLaunchKernelGGL(colsum_kernel, dim3(1024, 5), dim3(256), 0, s, cs);
+                FDGS_CHECK_LAUNCH();
+            }
             continue;
         }
         WGradK w;
@@ -1547,6 +1590,11 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         }
         hipLaunchKernelGGL(deform_wgrad_kernel, dim3((cn + w.chunk - 1) / w.chunk, nd), dim3(256), 0, s, w);
         FDGS_CHECK_LAUNCH();
+    }
+    const bool joined_early = side && colsum_done;
+    if (joined_early) {                         // the fold below reads the db2 copies written on the side stream
+        if (hipStreamWaitEvent(s, side->join, 0) != hipSuccess) return FDGS_ELAUNCH;
+        side = nullptr;
     }
     if (split) {
         OpacityFoldK of;
@@ -1574,7 +1622,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     }
     if (side) {                                 // join
         if (hipStreamWaitEvent(s, side->join, 0) != hipSuccess) return FDGS_ELAUNCH;
-    } else {
+    } else if (!joined_early) {
         rc = hex_tail(s);
         if (rc != FDGS_OK) return rc;
     }

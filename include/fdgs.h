@@ -314,9 +314,9 @@ typedef struct {
     size_t workspace_bytes;
     /* Optional, caller-owned, all three or none: a second hipStream_t and two hipEvent_t (created with
      * hipEventDisableTiming or not) on the device of `stream`.  With them the HexPlane scatter runs on
-     * side_stream beside the weight-gradient products: the call records fork_event on `stream`, makes side_stream
-     * wait for it, and makes `stream` wait for join_event before it returns, so the caller still sees one
-     * stream-ordered operation.  NULL: everything is enqueued on `stream`.  Two calls that may overlap in time
+     * side_stream beside the weight-gradient products: the call records fork_event on `stream` (twice: before and
+     * after its first pass over the points), makes side_stream wait for it, and makes `stream` wait for join_event
+     * before it returns, so the caller still sees one stream-ordered operation.  NULL: everything is enqueued on `stream`.  Two calls that may overlap in time
      * (different streams, different threads) need their own triple and their own workspace.                */
     void* side_stream; void* fork_event; void* join_event;
 } fdgs_deform_bwd_args;
