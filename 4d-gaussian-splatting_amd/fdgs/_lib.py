@@ -258,13 +258,16 @@ def check(status: int, what: str):
 # When set to a dict, every C-ABI call is bracketed by a pair of timing events
 # recorded on the stream the kernels are launched on (name -> [(start, end), ...]).
 PROFILE = None
+# None, or the set of entry points to bracket (the others are called as if PROFILE were None): a pair of events is two
+# more packets in the stream, and the kernels on either side of them start several microseconds apart
+PROFILE_ONLY = None
 
 
 def call(name, args):
     """Invoke entry point `name` with its argument struct on torch's current stream."""
     fn = getattr(lib, name)
     sp = torch.cuda.current_stream().cuda_stream
-    if PROFILE is None:
+    if PROFILE is None or (PROFILE_ONLY is not None and name not in PROFILE_ONLY):
         rc = fn(C.byref(args), sp)
     else:
         s = torch.cuda.Event(enable_timing=True)

@@ -55,6 +55,9 @@ def parse(argv=None):
     ap.add_argument("--render-frames", type=int, default=60, help="frames of the inference-only FPS legs (0 = skip)")
     ap.add_argument("--scale-mult", type=float, default=1.0, help="multiplier on the Gaussian scales (0.6 for the 2M case)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all-calls", action="store_true",
+                    help="event pairs around every entry point inside the timed region (default: only around the "
+                         "north-star kernel's; the others are timed in a leg of their own)")
     ap.add_argument("--fp32-mfma-steps", type=int, default=10,
                     help="steps of the extra leg that forms the deformation matrix products with fp32 MFMA (0 = skip)")
     ap.add_argument("--batch8-steps", type=int, default=6,
@@ -370,7 +373,10 @@ def main():
     with torch.no_grad():       # visible Gaussians of the first training view (recorded, not timed)
         visible = int((render(train_cams[rank % len(train_cams)], g, deforms, bg)["radii"] > 0).sum())
     sync()
+    # HIP events over the timed region around the north-star kernel's call only; the other entry points are timed the
+    # same way in a leg of their own below (events around all eleven calls of a step cost the step 2-3 %)
     _lib.PROFILE = {}
+    _lib.PROFILE_ONLY = None if args.profile_all_calls else {"fdgs_raster_blend_bwd"}
     rendered = []
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -379,6 +385,14 @@ def main():
     sync()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     prof, _lib.PROFILE = _lib.PROFILE, None
+    if _lib.PROFILE_ONLY is not None:      # kernel_ms of every entry point: the same steps continued, not timed as a whole
+        _lib.PROFILE, _lib.PROFILE_ONLY = {}, None
+        for i in range(min(args.steps, 40)):
+            step(batch(args.warmup + args.steps + i), iteration=1 + args.warmup + args.steps + i)
+        sync()
+        prof_all, _lib.PROFILE = _lib.PROFILE, None
+        prof_all["fdgs_raster_blend_bwd"] = prof.get("fdgs_raster_blend_bwd", [])
+        prof = prof_all
 
     # extra leg, not the headline: same step with the deformation matrix products on v_mfma_f32_32x32x2_f32
     # instead of the exact three-way bf16 split (both take, accumulate and return fp32)
