@@ -93,7 +93,7 @@ def render_sequence(views, pc, deforms, bg_color, keep_renders=False, to8b=True,
                 take(render(view, pc, deforms, bg_color, **render_kwargs)["render"])
         else:
             def begin(view):
-                settings, kwargs, _ = prepare(view, pc, deforms, bg_color, **render_kwargs)
+                settings, kwargs, _ = prepare(view, pc, deforms, bg_color, screenspace=False, **render_kwargs)
                 return rasterize_begin_call(settings, **kwargs)
             pending = begin(views[0])
             for i in range(len(views)):

@@ -22,15 +22,18 @@ from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 
 def prepare(viewpoint_camera, pc, deforms, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
-            stage="fine", cam_type=None, debug=False, convert_SHs_python=False, compute_cov3D_python=False):
+            stage="fine", cam_type=None, debug=False, convert_SHs_python=False, compute_cov3D_python=False,
+            screenspace=True):
     """Everything render() does before it calls the rasterizer (gaussian_renderer/__init__.py:21-102): the settings
     tuple, the deformation field, the activations.  Returns (raster_settings, the rasterizer's keyword arguments,
-    the gradient carrier of the 2-D means)."""
+    the gradient carrier of the 2-D means).  screenspace=False: no carrier is made (a caller that only wants the
+    image saves the [N,3] fill per frame); None is returned in its place."""
     means3D = pc.get_xyz
     dev = means3D.device
     # gradient carrier for the 2-D means (gaussian_renderer/__init__.py:27-31)
     # a leaf, so .grad is kept without retain_grad() and without the reference's "+ 0" launch
-    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=dev)
+    screenspace_points = (torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=dev)
+                          if screenspace else None)
 
     if cam_type != "PanopticSports":
         tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
