@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Per-queue timeline of one training step from a rocprofv3 --kernel-trace CSV: the kernels between two
-consecutive adam_kernel launches (the last complete step of the trace), with start offset, duration and the
+consecutive adam_kernel launches (by default the last complete step of the trace; a third argument -k picks the
+k-th step from the end), with start offset, duration and the
 hardware queue each ran on, so that it shows which of two concurrently running streams sets the step's length."""
 import csv
 import sys
@@ -35,4 +36,4 @@ def main(path, out=None, which=-2):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, int(sys.argv[3]) if len(sys.argv) > 3 else -2)

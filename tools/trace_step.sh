@@ -9,5 +9,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/prof/trace -o trace --output-
 cd $ROOT
 F=$(find $OUT/prof/trace -name '*kernel_trace.csv' | head -1)
 head -2 "$F" > $OUT/trace_head.txt
-python3 tools/timeline.py "$F" $OUT/${1:-timeline}.txt > /dev/null
+# the run ends with 10 steps that bracket every call with events (bench.py's kernel_ms leg): the step shown is one of
+# the timed region before them
+python3 tools/timeline.py "$F" $OUT/${1:-timeline}.txt -14 > /dev/null
 find $OUT/prof/trace -name '*kernel_trace.csv' -delete
