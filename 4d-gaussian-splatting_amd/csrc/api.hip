@@ -12,4 +12,4 @@ extern "C" const char* fdgs_strerror(int status) {
     }
 }
 
-extern "C" int fdgs_abi_version(void) { return 24; }
+extern "C" int fdgs_abi_version(void) { return 25; }

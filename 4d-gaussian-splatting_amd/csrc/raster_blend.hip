@@ -70,7 +70,7 @@ __device__ __forceinline__ bool exponent_reaches(float ex0, float ex1, float ey0
 __device__ __forceinline__ void reach4(float gx, float gy, uint32_t reach, float a2, float b1, float c2, float o,
                                        float bx, float by, bool valid,
                                        unsigned long long& m0, unsigned long long& m1, unsigned long long& m2,
-                                       unsigned long long& m3) {
+                                       unsigned long long& m3, uint32_t* bits = nullptr) {
     const float hx = __half2float(__ushort_as_half((unsigned short)(reach & 0xffffu)));
     const float hy = __half2float(__ushort_as_half((unsigned short)(reach >> 16)));
     const float x_hi = gx + hx, x_lo = gx - hx, y_hi = gy + hy, y_lo = gy - hy;
@@ -85,8 +85,10 @@ __device__ __forceinline__ void reach4(float gx, float gy, uint32_t reach, float
     const bool r1 = exponent_reaches(ex + 4.0f, ex + 7.0f, ey, ey + 3.0f, a2, b1, c2, inv_a2, inv_c2, tau);
     const bool r2 = exponent_reaches(ex, ex + 3.0f, ey + 4.0f, ey + 7.0f, a2, b1, c2, inv_a2, inv_c2, tau);
     const bool r3 = exponent_reaches(ex + 4.0f, ex + 7.0f, ey + 4.0f, ey + 7.0f, a2, b1, c2, inv_a2, inv_c2, tau);
-    m0 = __ballot(inx0 && iny0 && r0); m1 = __ballot(inx1 && iny0 && r1);
-    m2 = __ballot(inx0 && iny1 && r2); m3 = __ballot(inx1 && iny1 && r3);
+    const bool h0 = inx0 && iny0 && r0, h1 = inx1 && iny0 && r1, h2 = inx0 && iny1 && r2, h3 = inx1 && iny1 && r3;
+    m0 = __ballot(h0); m1 = __ballot(h1);
+    m2 = __ballot(h2); m3 = __ballot(h3);
+    if (bits) *bits = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
 }
 
 #define BL_LOG2E 1.4426950408889634f
@@ -141,7 +143,13 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
         my[lane * 2 + 1] = make_float4(sc2, g1.y, g1.z, g1.w);
         my2[lane] = make_float2(g2.x, g2.y);
         unsigned long long m0, m1, m2, m3;
-        reach4(g0.x, g0.y, __float_as_uint(g2.w), sa2, sb1, sc2, g1.y, bx, by, valid, m0, m1, m2, m3);
+        if (a.reach_masks) {            // kept for the backward pass (before the rows' saturation is applied)
+            uint32_t bits;
+            reach4(g0.x, g0.y, __float_as_uint(g2.w), sa2, sb1, sc2, g1.y, bx, by, valid, m0, m1, m2, m3, &bits);
+            if (valid) a.reach_masks[4 * (size_t)e + wave] = (uint8_t)bits;
+        } else {
+            reach4(g0.x, g0.y, __float_as_uint(g2.w), sa2, sb1, sc2, g1.y, bx, by, valid, m0, m1, m2, m3);
+        }
         // a row whose sixteen pixels are all saturated takes no more entries
         if ((live & 0xffffull) == 0ull) m0 = 0ull;
         if ((live & 0xffff0000ull) == 0ull) m1 = 0ull;
@@ -206,6 +214,35 @@ __device__ __forceinline__ float fold2(float x, float y, bool upper) {
     return keep + dpp_from<CTRL>(give);
 }
 
+// The first two steps of the butterfly for eight values (row_ror:8, then row_half_mirror) without the selects of
+// fold2: whether a lane keeps x or y is decided by bit 3 (bit 2) of its position in the row, i.e. by its DPP bank of
+// four lanes, so two adds with complementary bank masks write the two halves of one destination register -
+// v_add_f32_dpp d, x, x on the banks that keep x, then d, y, y on the others.  Twelve instructions for the six
+// folds instead of eighteen.  The s_nop covers the two wait states a DPP read needs after a vector write of the
+// same register (inside the block the dependent reads are at least three instructions behind their writes).
+// All 64 lanes must be active.
+__device__ __forceinline__ void butterfly_top(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                              float v7, float& b0, float& b1) {
+    float a0, a1, a2, a3;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %3, %12, %12 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %3, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %5, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %5, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
+}
+
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
@@ -261,7 +298,7 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     // position in its row) in every lane; even lanes store those eight, lane 1 of the row stores the ninth
     const int comp = (li == 1) ? 8 : (((li >> 1) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 3) & 1));
     const bool stores = (li & 1) == 0 || li == 1;
-    const bool up8 = (li & 8) != 0, up4 = (li & 4) != 0, up2 = (li & 2) != 0;
+    const bool up2 = (li & 2) != 0;
     // The rows' sums are collected per batch entry in LDS (float64: LDS float32 atomics are an order of magnitude
     // slower on this part) and handed to memory once per batch, nine consecutive floats per entry: the memory-side
     // atomic units are paced by requests, not bytes, and one request per row and step - four records per
@@ -284,7 +321,8 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
             g0 = geom4[3 * (size_t)id + 0];
             g1 = geom4[3 * (size_t)id + 1];
             gb = a.geom[FDGS_GEOM_FLOATS * (size_t)id + 8];
-            reach = __float_as_uint(a.geom[FDGS_GEOM_FLOATS * (size_t)id + 11]);
+            if (a.reach_masks) reach = a.reach_masks[4 * (size_t)(r_begin + (uint32_t)pos) + wave];
+            else reach = __float_as_uint(a.geom[FDGS_GEOM_FLOATS * (size_t)id + 11]);
             off = (unsigned long long)id * (FDGS_GEOM_FLOATS * sizeof(float));
         }
         const float sa2 = -BL_LOG2E * g0.z, sb1 = -BL_LOG2E * g0.w, sc2 = -BL_LOG2E * g1.x;
@@ -292,10 +330,16 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
         my[lane * 3 + 1] = make_float4(sc2, g1.y, g1.z, g1.w);
         my[lane * 3 + 2] = make_float4(gb, __uint_as_float((uint32_t)off), __uint_as_float((uint32_t)(off >> 32)), 0.f);
         unsigned long long m0, m1, m2, m3;
-        reach4(g0.x, g0.y, reach, sa2, sb1, sc2, g1.y, bx, by, valid, m0, m1, m2, m3);
         // entries behind a row's last contributor cannot contribute to it
-        m0 &= __ballot(pos < last0); m1 &= __ballot(pos < last1);
-        m2 &= __ballot(pos < last2); m3 &= __ballot(pos < last3);
+        if (a.reach_masks) {            // the forward pass's verdicts on this entry (it got at least as far as `last`)
+            const uint32_t bits = valid ? reach : 0u;
+            m0 = __ballot((bits & 1u) != 0u && pos < last0); m1 = __ballot((bits & 2u) != 0u && pos < last1);
+            m2 = __ballot((bits & 4u) != 0u && pos < last2); m3 = __ballot((bits & 8u) != 0u && pos < last3);
+        } else {
+            reach4(g0.x, g0.y, reach, sa2, sb1, sc2, g1.y, bx, by, valid, m0, m1, m2, m3);
+            m0 &= __ballot(pos < last0); m1 &= __ballot(pos < last1);
+            m2 &= __ballot(pos < last2); m3 &= __ballot(pos < last3);
+        }
         const int steps = build_lists(mylist, m0, m1, m2, m3, lane);
         const int jmin = hi - 1 - ncon;       // entry j of the batch is list position hi - 1 - j: before the pixel's last contributor <=> j > jmin
         for (int t = 0; t < steps; ++t) {
@@ -336,9 +380,8 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
             // Eight of the nine partial sums go through a transposing butterfly inside the 16-lane row: each exchange
             // step halves the number of live registers, and after the fourth every lane of the row holds the row's
             // total of one sum (which one: `comp`).  The ninth takes four plain exchange-and-add steps.
-            const float a0 = fold2<DPP_ROR8>(v_mx, v_my, up8), a1 = fold2<DPP_ROR8>(v_A, v_B, up8);
-            const float a2 = fold2<DPP_ROR8>(v_C, v_o, up8), a3 = fold2<DPP_ROR8>(v_r, v_g, up8);
-            const float b0 = fold2<DPP_HALF_MIRROR>(a0, a1, up4), b1 = fold2<DPP_HALF_MIRROR>(a2, a3, up4);
+            float b0, b1;
+            butterfly_top(v_mx, v_my, v_A, v_B, v_C, v_o, v_r, v_g, b0, b1);
             float r = fold2<DPP_XOR2>(b0, b1, up2);
             r += dpp_from<DPP_XOR1>(r);
             float s = v_b + dpp_from<DPP_XOR1>(v_b);

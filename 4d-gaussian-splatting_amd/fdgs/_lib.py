@@ -44,13 +44,15 @@ class BinSortArgs(C.Structure):
 class BlendFwdArgs(C.Structure):
     _fields_ = [("image_width", c_i32), ("image_height", c_i32),
                 ("ranges", c_p), ("point_list", c_p), ("geom", c_p), ("bg", c_p),
-                ("out_color", c_p), ("out_depth", c_p), ("final_T", c_p), ("n_contrib", c_p), ("tile_order", c_p)]
+                ("out_color", c_p), ("out_depth", c_p), ("final_T", c_p), ("n_contrib", c_p), ("tile_order", c_p),
+                ("reach_masks", c_p)]
 
 
 class BlendBwdArgs(C.Structure):
     _fields_ = [("image_width", c_i32), ("image_height", c_i32),
                 ("ranges", c_p), ("point_list", c_p), ("geom", c_p), ("bg", c_p),
-                ("final_T", c_p), ("n_contrib", c_p), ("dL_dcolor", c_p), ("dL_dgeom", c_p), ("tile_order", c_p)]
+                ("final_T", c_p), ("n_contrib", c_p), ("dL_dcolor", c_p), ("dL_dgeom", c_p), ("tile_order", c_p),
+                ("reach_masks", c_p)]
 
 
 class PreprocessBwdArgs(C.Structure):
@@ -230,7 +232,7 @@ SYMBOLS = {
 
 BINSORT_ALL, BINSORT_COUNT, BINSORT_FINISH = 0, 1, 2      # fdgs_binsort_args.phase
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 
 def _load():

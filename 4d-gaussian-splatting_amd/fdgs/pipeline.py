@@ -234,12 +234,16 @@ class ViewPipeline:
 
         def list_args():
             plist = ptr(self.vals_b)
+            # which pixel blocks an entry reaches: found by the forward blend kernel, read by the backward one; four
+            # bytes per entry in the buffer of the unsorted keys, which is free once the lists are built
+            masks = ptr(self.keys_a)
             return (_lib.BlendFwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.color),
-                                      ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib), ptr(self.tile_order)),
+                                      ptr(self.depth), ptr(self.final_T), ptr(self.n_contrib), ptr(self.tile_order),
+                                      masks),
                     # dgeom: zero from its allocation, re-zeroed by preprocess_bwd below
                     _lib.BlendBwdArgs(W, H, ptr(self.ranges), plist, ptr(self.geom), ptr(self.bg), ptr(self.final_T),
                                       ptr(self.n_contrib), ptr(self.grad_image), ptr(self.dgeom),
-                                      ptr(self.tile_order)))
+                                      ptr(self.tile_order), masks))
         bs = binsort_args() if self.capacity > 0 else None
         counted = False
         if bs is not None:              # the counting part of the tile lists runs while the list length travels

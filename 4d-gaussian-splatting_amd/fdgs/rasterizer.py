@@ -59,20 +59,24 @@ def _f32c(t):
 class RasterState:
     """Device buffers produced by the forward stages (kept for backward / inspection)."""
     __slots__ = ("geom", "radii", "tiles_touched", "point_offsets", "num_rendered", "keys_sorted", "vals_sorted",
-                 "ranges", "tile_order", "final_T", "n_contrib", "color", "depth", "cam")
+                 "ranges", "tile_order", "final_T", "n_contrib", "color", "depth", "cam", "reach_masks")
 
 
 class _PendingRaster:
     """A forward pass between its two halves: the preprocess call is enqueued and the list length requested."""
-    __slots__ = ("st", "ready", "r_host", "bufs", "args", "dims", "list_buffers", "call_args", "inputs", "counted")
+    __slots__ = ("st", "ready", "r_host", "bufs", "args", "dims", "list_buffers", "call_args", "inputs", "counted",
+                 "keep_masks")
 
 
 def rasterize_begin(means3D, shs, opacities, scales, rotations, S, colors_precomp=None, cov3D_precomp=None,
-                    activations=0):
+                    activations=0, keep_masks=False):
     """First half of rasterize_forward: stages 1-2 are enqueued, the list length is on its way to the host, every
     buffer whose size is known is allocated; nothing waits.  rasterize_finish(pending) does the rest.  (A playback
     loop enqueues the next frame's deformation and first half before it finishes the current frame, so the GPU has
-    work while the host waits for the length.)"""
+    work while the host waits for the length.)
+    keep_masks: the blend kernel records which pixel blocks every list entry reaches (RasterState.reach_masks, four
+    bytes per entry in the buffer the unsorted keys occupied until the sort); the backward then reads them instead
+    of repeating the test.  For passes that a backward follows."""
     _lib.require_gpu(means3D, shs, opacities, scales, rotations, colors_precomp, cov3D_precomp, S.bg, S.viewmatrix,
                      S.projmatrix, S.campos)
     dev = means3D.device
@@ -125,9 +129,11 @@ def rasterize_begin(means3D, shs, opacities, scales, rotations, S, colors_precom
         b = _lib.BinSortArgs(N, W, H, 0, ptr(st.geom), ptr(st.point_offsets), ptr(keys_a), ptr(vals_a), ptr(keys_s),
                              ptr(vals_s), ptr(st.ranges), ptr(sort_ws), ws_bytes, 0, 0, ptr(st.tile_order))
         c = _lib.BlendFwdArgs(W, H, ptr(st.ranges), ptr(vals_s), ptr(st.geom), ptr(bg), ptr(st.color), ptr(st.depth),
-                              ptr(st.final_T), ptr(st.n_contrib), ptr(st.tile_order))
+                              ptr(st.final_T), ptr(st.n_contrib), ptr(st.tile_order),
+                              ptr(keys_a) if keep_masks else None)
         return b, c
     p.list_buffers, p.call_args = list_buffers, call_args
+    p.keep_masks = bool(keep_masks)
     p.bufs = list_buffers(_LIST_CAPACITY) if _LIST_CAPACITY > 0 else None
     # ... and so are the argument blocks of the two calls that follow the wait: the GPU is idle until they are made
     p.args = call_args(p.bufs) if p.bufs is not None else (None, None)
@@ -168,6 +174,7 @@ def rasterize_finish(p, keep_keys=False):
         b, c = p.call_args(bufs)
         counted = False                 # another workspace: the counts are taken again
     st.keys_sorted, st.vals_sorted = bufs[3], bufs[4]
+    st.reach_masks = bufs[1] if p.keep_masks else None      # the unsorted keys' buffer, free once the lists are built
     b.num_rendered, b.depth_bits_min, b.depth_bits_max = R, dmin, dmax
     b.phase = _lib.BINSORT_FINISH if counted else _lib.BINSORT_ALL
     if R == 0:          # no list entries: the list pointer is NULL (the library then also accepts the NULL geom of an empty scene)
@@ -181,12 +188,13 @@ def rasterize_finish(p, keep_keys=False):
 
 
 def rasterize_forward(means3D, shs, opacities, scales, rotations, S, keep_keys=False, colors_precomp=None,
-                      cov3D_precomp=None, activations=0):
+                      cov3D_precomp=None, activations=0, keep_masks=False):
     """Runs stages 1-6 through the C ABI and returns a RasterState.  Either shs or colors_precomp [N,3],
     either (scales, rotations) or cov3D_precomp [N,6].  `activations` (ACT_* flags of fdgs._lib) marks
     scales / rotations / opacities as raw parameters whose activation the preprocess kernel applies."""
     return rasterize_finish(rasterize_begin(means3D, shs, opacities, scales, rotations, S, colors_precomp=colors_precomp,
-                                            cov3D_precomp=cov3D_precomp, activations=activations), keep_keys=keep_keys)
+                                            cov3D_precomp=cov3D_precomp, activations=activations,
+                                            keep_masks=keep_masks), keep_keys=keep_keys)
 
 
 def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, colors_precomp=None, cov3D_precomp=None,
@@ -198,7 +206,8 @@ def rasterize_backward(st, grad_color, means3D, shs, scales, rotations, S, color
     dgeom = torch.zeros(N, _lib.GEOM_FLOATS, device=dev, dtype=torch.float32)
     gc = _f32c(grad_color)
     a = _lib.BlendBwdArgs(W, H, ptr(st.ranges), ptr(st.vals_sorted) if st.num_rendered > 0 else None, ptr(st.geom), ptr(bg), ptr(st.final_T),
-                          ptr(st.n_contrib), ptr(gc), ptr(dgeom), ptr(st.tile_order))
+                          ptr(st.n_contrib), ptr(gc), ptr(dgeom), ptr(st.tile_order),
+                          ptr(getattr(st, "reach_masks", None)) if st.num_rendered > 0 else None)
     _lib.call("fdgs_raster_blend_bwd", a)
     d_means3D = torch.empty(N, 3, device=dev, dtype=torch.float32)
     d_means2D = torch.empty(N, 3, device=dev, dtype=torch.float32)
@@ -230,7 +239,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         opt = lambda t: None if t is None else _f32c(t)
         m3, sh, cp = _f32c(means3D), opt(shs), opt(colors_precomp)
         op, sc, ro, cv = _f32c(opacities).reshape(-1), opt(scales), opt(rotations), opt(cov3D_precomp)
-        st = rasterize_forward(m3, sh, op, sc, ro, S, colors_precomp=cp, cov3D_precomp=cv, activations=activations)
+        st = rasterize_forward(m3, sh, op, sc, ro, S, colors_precomp=cp, cov3D_precomp=cv, activations=activations,
+                               keep_masks=any(ctx.needs_input_grad))
         ctx.S = S
         ctx.activations = activations
         # the context keeps what the backward reads (geom, list, ranges, final_T, n_contrib) and none of the

@@ -158,6 +158,11 @@ typedef struct {
     uint32_t* n_contrib;             /* [H,W] 1-based list position of the last contributor */
     const uint32_t* tile_order;      /* NULL, or [tiles]: a permutation of the tile ids; workgroup i takes tile
                                         tile_order[i] (longest lists first shortens the tail of the launch) */
+    /* NULL, or [R][4] bytes: for every list entry and each of its tile's four 8x8 quadrants, which of the
+     * quadrant's four 4x4 pixel blocks the entry's 1/255-alpha ellipse reaches (bits 0-3).  Written for the
+     * entries a quadrant gets to before all its pixels are saturated - a superset of what the backward asks for.
+     * fdgs_raster_blend_bwd given the same array reads the bits instead of repeating the test.           */
+    uint8_t* reach_masks;
 } fdgs_blend_fwd_args;
 
 int fdgs_raster_blend_fwd(const fdgs_blend_fwd_args* a, void* stream);
@@ -179,6 +184,7 @@ typedef struct {
      *   [6..8] dL/drgb  [9..11] unused                                            */
     float* dL_dgeom;
     const uint32_t* tile_order;      /* as in fdgs_blend_fwd_args */
+    const uint8_t* reach_masks;      /* NULL, or the array fdgs_raster_blend_fwd filled for the same lists */
 } fdgs_blend_bwd_args;
 
 int fdgs_raster_blend_bwd(const fdgs_blend_bwd_args* a, void* stream);

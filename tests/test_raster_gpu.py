@@ -250,6 +250,33 @@ def test_backward(name):
         assert rel <= GRAD_TOL, f"{k}: rel {rel:.3e}"
 
 
+@pytest.mark.parametrize("name", ["ragged", "medium", "n4096"])
+def test_backward_with_the_forward_pass_reach_masks(name):
+    """The backward blend kernel either repeats the test "which 4x4 pixel blocks does this entry reach" or reads the
+    forward kernel's verdicts (reach_masks): both ways give the same gradients (float atomics: to rounding), and the
+    recorded bits are the ones the backward's own test finds."""
+    from fdgs import rasterizer as fr
+    c = rc.make_case(name)
+    dev = torch.device("cuda:0")
+    S = _to_dev(c["S"], dev)
+    ins = [c["means3D"].to(dev), c["shs"].to(dev), c["opacities"].reshape(-1).to(dev).contiguous(),
+           c["scales"].to(dev), c["rotations"].to(dev)]
+    gout = torch.randn(3, S.image_height, S.image_width, generator=torch.Generator().manual_seed(3)).to(dev)
+    grads = []
+    for keep in (False, True):
+        st = fr.rasterize_forward(*ins, S, keep_masks=keep)
+        assert (st.reach_masks is not None) == keep
+        grads.append(fr.rasterize_backward(st, gout, ins[0], ins[1], ins[3], ins[4], S))
+    torch.cuda.synchronize()
+    for k, ref in grads[0].items():
+        got = grads[1][k]
+        if ref is None:
+            assert got is None
+            continue
+        rel = float((got - ref).abs().max() / (ref.abs().max() + 1e-30))
+        assert rel <= 1e-5, f"{k}: rel {rel:.3e}"
+
+
 def test_no_grad_and_empty():
     """Works under torch.no_grad (render.py:136) and with nothing visible."""
     from fdgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
