@@ -19,6 +19,10 @@
 #define BL_SLOTS 65                                // 64 entries of a batch + the null record
 #define BL_NULL 64
 
+// 64-bit lane mask of a predicate (__ballot takes an int: the predicate would be turned into 0 / 1 in a vector
+// register and compared again)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -86,8 +90,8 @@ __device__ __forceinline__ void reach4(float gx, float gy, uint32_t reach, float
     const bool r2 = exponent_reaches(ex, ex + 3.0f, ey + 4.0f, ey + 7.0f, a2, b1, c2, inv_a2, inv_c2, tau);
     const bool r3 = exponent_reaches(ex + 4.0f, ex + 7.0f, ey + 4.0f, ey + 7.0f, a2, b1, c2, inv_a2, inv_c2, tau);
     const bool h0 = inx0 && iny0 && r0, h1 = inx1 && iny0 && r1, h2 = inx0 && iny1 && r2, h3 = inx1 && iny1 && r3;
-    m0 = __ballot(h0); m1 = __ballot(h1);
-    m2 = __ballot(h2); m3 = __ballot(h3);
+    m0 = ballot64(h0); m1 = ballot64(h1);
+    m2 = ballot64(h2); m3 = ballot64(h3);
     if (bits) *bits = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
 }
 
@@ -127,7 +131,7 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
     bool done = !inside;
 
     for (uint32_t base = r_begin; base < r_end; base += 64) {
-        const unsigned long long live = __ballot(!done);
+        const unsigned long long live = ballot64(!done);
         if (live == 0ull) break;
         const uint32_t e = base + lane;
         const bool valid = e < r_end;
@@ -164,21 +168,24 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
             const float u = c0.z * dx, w = c1.x * dy, bdx = c0.w * dx;
             const float power = 0.5f * (u * dx + w * dy) + bdx * dy;      // log2(e) x the exponent
             const float alpha = fminf(FDGS_ALPHA_MAX, c1.y * __builtin_amdgcn_exp2f(power));
-            if (!done && power <= 0.0f && alpha >= FDGS_ALPHA_MIN) {
+            // No divergent branch (the two nested ones cost more scalar mask instructions per step than the step has
+            // vector instructions): a lane that does not take the entry adds weight 0 and keeps T and `last`.
+            {
+                const bool ok = !done && power <= 0.0f && alpha >= FDGS_ALPHA_MIN;
                 const float test_T = T * (1.0f - alpha);
-                if (test_T < FDGS_T_STOP) {
-                    done = true;
-                } else {
-                    const float wgt = alpha * T;
-                    Cr += c1.z * wgt;
-                    Cg += c1.w * wgt;
-                    Cb += c2.x * wgt;
-                    D += c2.y * wgt;
-                    T = test_T;
-                    last = (base - r_begin) + (uint32_t)j + 1u;
-                }
+                const bool stop = ok && test_T < FDGS_T_STOP;
+                const bool take = ok && !stop;
+                done = done || stop;
+                const float wgt = take ? alpha * T : 0.0f;
+                Cr += c1.z * wgt;
+                Cg += c1.w * wgt;
+                Cb += c2.x * wgt;
+                D += c2.y * wgt;
+                T = take ? test_T : T;
+                last = take ? (base - r_begin) + (uint32_t)j + 1u : last;
             }
-            if (__ballot(!done) == 0ull) break;
+            // (no test for "all pixels saturated" per step: it cost two vector and six scalar instructions in every
+            // step to save half a batch's steps once in a wave's life; the test at the head of the batch remains)
         }
     }
     if (inside) {
@@ -333,12 +340,12 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
         // entries behind a row's last contributor cannot contribute to it
         if (a.reach_masks) {            // the forward pass's verdicts on this entry (it got at least as far as `last`)
             const uint32_t bits = valid ? reach : 0u;
-            m0 = __ballot((bits & 1u) != 0u && pos < last0); m1 = __ballot((bits & 2u) != 0u && pos < last1);
-            m2 = __ballot((bits & 4u) != 0u && pos < last2); m3 = __ballot((bits & 8u) != 0u && pos < last3);
+            m0 = ballot64((bits & 1u) != 0u && pos < last0); m1 = ballot64((bits & 2u) != 0u && pos < last1);
+            m2 = ballot64((bits & 4u) != 0u && pos < last2); m3 = ballot64((bits & 8u) != 0u && pos < last3);
         } else {
             reach4(g0.x, g0.y, reach, sa2, sb1, sc2, g1.y, bx, by, valid, m0, m1, m2, m3);
-            m0 &= __ballot(pos < last0); m1 &= __ballot(pos < last1);
-            m2 &= __ballot(pos < last2); m3 &= __ballot(pos < last3);
+            m0 &= ballot64(pos < last0); m1 &= ballot64(pos < last1);
+            m2 &= ballot64(pos < last2); m3 &= ballot64(pos < last3);
         }
         const int steps = build_lists(mylist, m0, m1, m2, m3, lane);
         const int jmin = hi - 1 - ncon;       // entry j of the batch is list position hi - 1 - j: before the pixel's last contributor <=> j > jmin
@@ -352,7 +359,7 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
             const float G = __builtin_amdgcn_exp2f(power);
             const float alpha = fminf(FDGS_ALPHA_MAX, o * G);
             const bool contrib = (j > jmin) && power <= 0.0f && alpha >= FDGS_ALPHA_MIN;
-            if (__ballot(contrib) == 0ull) continue;
+            if (ballot64(contrib) == 0ull) continue;
             // No divergent branch: a lane that does not contribute runs the same arithmetic with alpha = 0 and
             // G = 0, which leaves its state unchanged bit for bit (T * rcp(1) = T; the colour behind folds as
             // 0 * c + 1 * acc = acc) and makes all nine of its partial sums exact zeros.
