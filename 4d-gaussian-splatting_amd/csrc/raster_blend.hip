@@ -114,16 +114,14 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
     const uint32_t r_begin = a.ranges[2 * tile], r_end = a.ranges[2 * tile + 1];
     const float4* __restrict__ geom4 = reinterpret_cast<const float4*>(a.geom);
 
-    __shared__ float4 staged[4][BL_SLOTS * 2];
-    __shared__ float2 staged2[4][BL_SLOTS];                 // forward: (b, depth)
+    __shared__ float4 staged[4][BL_SLOTS * 3];              // (x y a2 b1) (c2 o r g) (b depth - -): one address per entry
     float4* __restrict__ my = staged[wave];
-    float2* __restrict__ my2 = staged2[wave];
     __shared__ unsigned char lists[4][4 * 64];              // per wave: the four rows' survivor lists of a batch
     unsigned char* __restrict__ mylist = lists[wave];
     if (lane == 0) {
-        my[BL_NULL * 2 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
-        my[BL_NULL * 2 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);      // opacity 0
-        my2[BL_NULL] = make_float2(0.f, 0.f);
+        my[BL_NULL * 3 + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        my[BL_NULL * 3 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);      // opacity 0
+        my[BL_NULL * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     float T = 1.0f, Cr = 0.f, Cg = 0.f, Cb = 0.f, D = 0.f;
@@ -143,9 +141,9 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
             g2 = geom4[3 * (size_t)id + 2];
         }
         const float sa2 = -BL_LOG2E * g0.z, sb1 = -BL_LOG2E * g0.w, sc2 = -BL_LOG2E * g1.x;
-        my[lane * 2 + 0] = make_float4(g0.x, g0.y, sa2, sb1);
-        my[lane * 2 + 1] = make_float4(sc2, g1.y, g1.z, g1.w);
-        my2[lane] = make_float2(g2.x, g2.y);
+        my[lane * 3 + 0] = make_float4(g0.x, g0.y, sa2, sb1);
+        my[lane * 3 + 1] = make_float4(sc2, g1.y, g1.z, g1.w);
+        *reinterpret_cast<float2*>(&my[lane * 3 + 2]) = make_float2(g2.x, g2.y);
         unsigned long long m0, m1, m2, m3;
         if (a.reach_masks) {            // kept for the backward pass (before the rows' saturation is applied)
             uint32_t bits;
@@ -160,10 +158,11 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
         if ((live & 0xffff00000000ull) == 0ull) m2 = 0ull;
         if ((live & 0xffff000000000000ull) == 0ull) m3 = 0ull;
         const int steps = build_lists(mylist, m0, m1, m2, m3, lane);
+        int last_j = -1;                // batch position of the last entry this pixel took in this batch
         for (int t = 0; t < steps; ++t) {
             const int j = (int)mylist[4 * t + row];
-            const float4 c0 = my[j * 2 + 0], c1 = my[j * 2 + 1];
-            const float2 c2 = my2[j];
+            const float4 c0 = my[j * 3 + 0], c1 = my[j * 3 + 1];
+            const float2 c2 = *reinterpret_cast<const float2*>(&my[j * 3 + 2]);
             const float dx = c0.x - pxf, dy = c0.y - pyf;
             const float u = c0.z * dx, w = c1.x * dy, bdx = c0.w * dx;
             const float power = 0.5f * (u * dx + w * dy) + bdx * dy;      // log2(e) x the exponent
@@ -182,11 +181,12 @@ blend_fwd_kernel(fdgs_blend_fwd_args a, int tiles_x) {
                 Cb += c2.x * wgt;
                 D += c2.y * wgt;
                 T = take ? test_T : T;
-                last = take ? (base - r_begin) + (uint32_t)j + 1u : last;
+                last_j = take ? j : last_j;
             }
             // (no test for "all pixels saturated" per step: it cost two vector and six scalar instructions in every
             // step to save half a batch's steps once in a wave's life; the test at the head of the batch remains)
         }
+        if (last_j >= 0) last = (base - r_begin) + (uint32_t)last_j + 1u;
     }
     if (inside) {
         const size_t pix = (size_t)pyi * W + pxi, plane = (size_t)W * H;
