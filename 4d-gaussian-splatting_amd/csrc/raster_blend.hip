@@ -48,7 +48,7 @@ __device__ __forceinline__ int build_lists(unsigned char* __restrict__ lists, un
     if ((m2 >> lane) & 1ull) lists[4 * r2 + 2] = (unsigned char)lane;
     if ((m3 >> lane) & 1ull) lists[4 * r3 + 3] = (unsigned char)lane;
     const int n0 = __popcll(m0), n1 = __popcll(m1), n2 = __popcll(m2), n3 = __popcll(m3);
-    return max(max(n0, n1), max(n2, n3));
+    return __builtin_amdgcn_readfirstlane(max(max(n0, n1), max(n2, n3)));     // wave-uniform: a scalar loop count
 }
 
 // Can the splat's alpha reach 1/255 at some pixel centre of the rectangle [ex0, ex1] x [ey0, ey1] (coordinates
@@ -226,7 +226,8 @@ __device__ __forceinline__ float fold2(float x, float y, bool upper) {
 // four lanes, so two adds with complementary bank masks write the two halves of one destination register -
 // v_add_f32_dpp d, x, x on the banks that keep x, then d, y, y on the others.  Twelve instructions for the six
 // folds instead of eighteen.  The s_nop covers the two wait states a DPP read needs after a vector write of the
-// same register (inside the block the dependent reads are at least three instructions behind their writes).
+// same register (inside the block the dependent reads are at least three instructions behind their writes; the
+// results are next read by plain vector instructions, which need none).
 // All 64 lanes must be active.
 __device__ __forceinline__ void butterfly_top(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
                                               float v7, float& b0, float& b1) {
@@ -244,8 +245,7 @@ __device__ __forceinline__ void butterfly_top(float v0, float v1, float v2, floa
         "v_add_f32_dpp %4, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
         "v_add_f32_dpp %4, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
         "v_add_f32_dpp %5, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %5, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 1"
+        "v_add_f32_dpp %5, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xa"
         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1)
         : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
 }
@@ -292,7 +292,7 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     const int last2 = __builtin_amdgcn_readlane(row_last, 32), last3 = __builtin_amdgcn_readlane(row_last, 48);
     const int wave_last = max(max(last0, last1), max(last2, last3));
 
-    __shared__ float4 staged[4][BL_SLOTS * 3];          // (x y a2 b1) (c2 o r g) (b, gradient-record byte offset lo, hi, -)
+    __shared__ float4 staged[4][BL_SLOTS * 3];          // (x y a2 b1) (c2 o r g) (b, address of the gradient record lo, hi, -)
     float4* __restrict__ my = staged[wave];
     __shared__ unsigned char lists[4][4 * 64];          // per wave: the four rows' survivor lists of a batch
     unsigned char* __restrict__ mylist = lists[wave];
@@ -330,7 +330,7 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
             gb = a.geom[FDGS_GEOM_FLOATS * (size_t)id + 8];
             if (a.reach_masks) reach = a.reach_masks[4 * (size_t)(r_begin + (uint32_t)pos) + wave];
             else reach = __float_as_uint(a.geom[FDGS_GEOM_FLOATS * (size_t)id + 11]);
-            off = (unsigned long long)id * (FDGS_GEOM_FLOATS * sizeof(float));
+            off = (unsigned long long)dbase + (unsigned long long)id * (FDGS_GEOM_FLOATS * sizeof(float));
         }
         const float sa2 = -BL_LOG2E * g0.z, sb1 = -BL_LOG2E * g0.w, sc2 = -BL_LOG2E * g1.x;
         my[lane * 3 + 0] = make_float4(g0.x, g0.y, sa2, sb1);
@@ -412,7 +412,7 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
                 const float4 rec = my[e * 3 + 2];
                 const unsigned long long goff = (unsigned long long)__float_as_uint(rec.y) |
                                                 ((unsigned long long)__float_as_uint(rec.z) << 32);
-                atomicAdd(reinterpret_cast<float*>(dbase + goff + 4 * (q - 9 * e)), f);
+                atomicAdd(reinterpret_cast<float*>(goff + 4 * (q - 9 * e)), f);
             }
         }
     }
