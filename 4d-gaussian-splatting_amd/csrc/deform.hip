@@ -1258,6 +1258,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             yfeat = reinterpret_cast<const u32x4*>(ws_yfeat);
         }
         int per = (chunks + 1023) / 1024;
+        per = (per + 3) / 4 * 4;                // the kernel walks a range in groups of four chunks
         if (per < 4) per = 4;
         WGradSK w1;
         w1.n = n;
@@ -1517,6 +1518,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             }
             static const int wg_ranges = getenv("FDGS_WGRAD_RANGES") ? atoi(getenv("FDGS_WGRAD_RANGES")) : 204;
             int per = (chunks + wg_ranges - 1) / wg_ranges;     // about a thousand workgroups of four waves
+            per = (per + 3) / 4 * 4;                            // the kernel walks a range in groups of four chunks
             if (per < 4) per = 4;
             WGradSK w4;
             w4.n = cn;

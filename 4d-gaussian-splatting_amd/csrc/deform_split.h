@@ -964,8 +964,6 @@ deform_wgrad_split_kernel(WGradSK a) {
     __shared__ __align__(16) float fly_cot[4][64];
     __shared__ __align__(16) unsigned fly_msk[4][32];
     const bool fly = d.cot != nullptr;
-    float cotr[XA];
-    unsigned mskr[XA];
     float w2v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (fly) {                                   // w2 == NULL: unit weights (X = mask * cot, k = 1)
 #pragma unroll
@@ -982,96 +980,109 @@ deform_wgrad_split_kernel(WGradSK a) {
     int cot_slot = lane;
     if (fly && lane < 16 * d.k) cot_slot = (lane % d.k) * 16 + lane / d.k;
     const int msk_slot = ((lane & 1) << 4) | ((lane >> 1) & 15);
-    auto load_fly = [&](int ch, float& co, unsigned& mo) {
-        const int pb = ch * 16;
-        co = 0.0f; mo = 0u;
-        if (lane < 16 * d.k && pb + lane / d.k < a.n) co = d.cot[(size_t)pb * d.k + lane];
-        if (lane < 32 && pb + (lane >> 1) < a.n) {
-            const uint2 m = d.mask[(size_t)pb * 2 + lane];
-            mo = (mb >> 1) ? m.y : m.x;
-        }
-    };
-    float xr[XA][8];
-    auto load_x = [&](int ch, float* xo) {
-        const int pb = ch * 16;
-        if (pb + 16 <= a.n) {
+    // Every prefetch below is an unconditional load from a clamped address (a chunk index beyond the range's end
+    // repeats the last chunk, a point beyond n repeats the last point; such values are zeroed where they are
+    // consumed), the loop body has no branch around a load, and the two ways of getting X are two instances of the
+    // loop under one branch at the top.  Loads inside branches - even uniform ones - made the compiler's wait-count
+    // bookkeeping pessimistic at the joins: it waited for ALL outstanding loads once per chunk, and a chunk then
+    // took one memory latency however far ahead its operands were requested.  The price: a range whose length is
+    // not a multiple of XA runs up to XA - 1 chunks of zeros (the host makes the ranges multiples of XA, so this
+    // happens in the last range only).
+    const int ch_last = ch_end - 1;
+    int it = 0;
+    auto run = [&](auto fly_c) {
+        constexpr bool FLY = decltype(fly_c)::value;
+        float cotr[XA];
+        unsigned mskr[XA];
+        float xr[XA][8];
+        auto load_fly = [&](int ch, float& co, unsigned& mo) {
+            const int pb = min(ch, ch_last) * 16;
+            const long long cot_last = (long long)a.n * d.k - 1, msk_last = 2ll * a.n - 1;
+            const long long ci = (long long)pb * d.k + lane, mi = (long long)pb * 2 + lane;
+            const float cv = d.cot[ci < cot_last ? ci : cot_last];
+            const uint2 m = d.mask[mi < msk_last ? mi : msk_last];
+            const bool real = ch <= ch_last;
+            co = (real && lane < 16 * d.k && ci <= cot_last) ? cv : 0.0f;
+            mo = (real && lane < 32 && mi <= msk_last) ? ((mb >> 1) ? m.y : m.x) : 0u;
+        };
+        auto load_x = [&](int ch, float* xo) {
+            const int pb = min(ch, ch_last) * 16;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xo[e] = X[(size_t)(pb + 8 * g + e) * d.ldx];
-        } else {
+            for (int e = 0; e < 8; ++e) xo[e] = X[(size_t)min(pb + 8 * g + e, a.n - 1) * d.ldx];
+        };
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int p = pb + 8 * g + e;
-                xo[e] = p < a.n ? X[(size_t)p * d.ldx] : 0.0f;
-            }
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < XA; ++i)
-        if (ch_begin + i < ch_end) {
-            if (fly) load_fly(ch_begin + i, cotr[i], mskr[i]);
+        for (int i = 0; i < XA; ++i) {
+            if constexpr (FLY) load_fly(ch_begin + i, cotr[i], mskr[i]);
             else load_x(ch_begin + i, xr[i]);
         }
-    Split3 ystage;                               // this wave's share (column block mb) of the next chunk
-    if (mb < NB) {
-        ystage = sfrag_load(d.ysplit, ch_begin, NB, mb, lane);
-        ybuf[0][(mb * 3 + 0) * 64 + lane] = ystage.h;
-        ybuf[0][(mb * 3 + 1) * 64 + lane] = ystage.m;
-        ybuf[0][(mb * 3 + 2) * 64 + lane] = ystage.l;
-    }
-    __syncthreads();
-    // X of chunk `ch` as split operand pieces, from ring stage i (static); refills the stage for chunk ch + XA.
-    // It is called for the NEXT chunk right after the current chunk's MFMAs are issued, so that its vector and
-    // LDS work runs under the matrix pipeline.
-    auto fly_x = [&](auto kc, float* xv) {                 // kc: the head's output count as a compile-time value
-        constexpr int K = decltype(kc)::value;
-        const float4* cq = reinterpret_cast<const float4*>(&fly_cot[mb][0]) + 2 * g;
-        const uint4* mq = reinterpret_cast<const uint4*>(&fly_msk[mb][0]) + 4 * fly_half + 2 * g;
-        float x[8];
+        // This wave's share (column block mb) of the Y pieces of the next XA chunks, requested as far ahead as X
+        // (loads return in order: a piece requested in the iteration that hands it to LDS would make that iteration
+        // wait for every older request too).  Ring slot k % XA holds chunk ch_begin + k.
+        Split3 yst[XA];
+        if (NB == 4 || mb < NB) {
+            const Split3 y0 = sfrag_load(d.ysplit, ch_begin, NB, mb, lane);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = 0.0f;
-#pragma unroll
-        for (int o = 0; o < K; ++o) {
-            const float4 lo = cq[4 * o], hi = cq[4 * o + 1];
-            const float cv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) x[e] = fmaf(w2v[o], cv[e], x[e]);
+            for (int k = 1; k <= XA; ++k) yst[k % XA] = sfrag_load(d.ysplit, min(ch_begin + k, ch_last), NB, mb, lane);
+            ybuf[0][(mb * 3 + 0) * 64 + lane] = y0.h;
+            ybuf[0][(mb * 3 + 1) * 64 + lane] = y0.m;
+            ybuf[0][(mb * 3 + 2) * 64 + lane] = y0.l;
         }
-        const uint4 mlo = mq[0], mhi = mq[1];
-        const unsigned mw[8] = {mlo.x, mlo.y, mlo.z, mlo.w, mhi.x, mhi.y, mhi.z, mhi.w};
+        __syncthreads();
+        // X of chunk `ch` as split operand pieces, from ring stage i (static); refills the stage for chunk ch + XA.
+        // It is called for the NEXT chunk right after the current chunk's MFMAs are issued, so that its vector and
+        // LDS work runs under the matrix pipeline.
+        auto fly_x = [&](auto kc, float* xv) {                 // kc: the head's output count as a compile-time value
+            constexpr int K = decltype(kc)::value;
+            const float4* cq = reinterpret_cast<const float4*>(&fly_cot[mb][0]) + 2 * g;
+            const uint4* mq = reinterpret_cast<const uint4*>(&fly_msk[mb][0]) + 4 * fly_half + 2 * g;
+            float x[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int masked = __builtin_amdgcn_sbfe((int)mw[e], fly_bit, 1);
-            xv[e] = __uint_as_float(__float_as_uint(x[e]) & ~(unsigned)masked);
-        }
-    };
-    auto make_x = [&](int ch, int i) -> Split3 {
-        float xv[8];
-        if (fly) {
-            fly_cot[mb][cot_slot] = cotr[i];
-            if (lane < 32) fly_msk[mb][msk_slot] = mskr[i];
-            if (ch + XA < ch_end) load_fly(ch + XA, cotr[i], mskr[i]);
-            if (d.k == 4) fly_x(std::integral_constant<int, 4>{}, xv);
-            else if (d.k == 3) fly_x(std::integral_constant<int, 3>{}, xv);
-            else if (d.k == 2) fly_x(std::integral_constant<int, 2>{}, xv);
-            else fly_x(std::integral_constant<int, 1>{}, xv);
-        } else {
+            for (int e = 0; e < 8; ++e) x[e] = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xv[e] = xr[i][e];
-            if (ch + XA < ch_end) load_x(ch + XA, xr[i]);
-        }
+            for (int o = 0; o < K; ++o) {
+                const float4 lo = cq[4 * o], hi = cq[4 * o + 1];
+                const float cv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bsum += xv[e];
-        return split8<false>(xv);
-    };
-    int it = 0;
-    Split3 xs = make_x(ch_begin, 0);
-    for (int ch0 = ch_begin; ch0 < ch_end; ch0 += XA) {
+                for (int e = 0; e < 8; ++e) x[e] = fmaf(w2v[o], cv[e], x[e]);
+            }
+            const uint4 mlo = mq[0], mhi = mq[1];
+            const unsigned mw[8] = {mlo.x, mlo.y, mlo.z, mlo.w, mhi.x, mhi.y, mhi.z, mhi.w};
 #pragma unroll
-        for (int i = 0; i < XA; ++i) {           // ring position i is static: the stages stay in registers
-            const int ch = ch0 + i;
-            if (ch < ch_end) {                   // uniform over the workgroup
+            for (int e = 0; e < 8; ++e) {
+                const int masked = __builtin_amdgcn_sbfe((int)mw[e], fly_bit, 1);
+                xv[e] = __uint_as_float(__float_as_uint(x[e]) & ~(unsigned)masked);
+            }
+        };
+        auto make_x = [&](int ch, int i) -> Split3 {
+            float xv[8];
+            if constexpr (FLY) {
+                fly_cot[mb][cot_slot] = cotr[i];
+                if (lane < 32) fly_msk[mb][msk_slot] = mskr[i];
+                load_fly(ch + XA, cotr[i], mskr[i]);
+                if (d.k == 4) fly_x(std::integral_constant<int, 4>{}, xv);
+                else if (d.k == 3) fly_x(std::integral_constant<int, 3>{}, xv);
+                else if (d.k == 2) fly_x(std::integral_constant<int, 2>{}, xv);
+                else fly_x(std::integral_constant<int, 1>{}, xv);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = xr[i][e];
+                if (ch * 16 + 16 > a.n || ch > ch_last) {    // a partial or a padding chunk: rows beyond the data are zero
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (ch > ch_last || ch * 16 + 8 * g + e >= a.n) xv[e] = 0.0f;
+                }
+                load_x(ch + XA, xr[i]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bsum += xv[e];
+            return split8<false>(xv);
+        };
+        Split3 xs = make_x(ch_begin, 0);
+        for (int ch0 = ch_begin; ch0 < ch_end; ch0 += XA) {
+#pragma unroll
+            for (int i = 0; i < XA; ++i) {           // ring position i is static: the stages stay in registers
+                const int ch = ch0 + i;
                 const int cur = it & 1;
-                if (ch + 1 < ch_end && mb < NB) ystage = sfrag_load(d.ysplit, ch + 1, NB, mb, lane);
                 Split3 ys[NB];
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
@@ -1081,17 +1092,21 @@ deform_wgrad_split_kernel(WGradSK a) {
                 }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) acc[nb] = mma_split(xs, ys[nb], acc[nb]);
-                if (ch + 1 < ch_end) xs = make_x(ch + 1, (i + 1) % XA);
-                if (ch + 1 < ch_end && mb < NB) {
-                    ybuf[cur ^ 1][(mb * 3 + 0) * 64 + lane] = ystage.h;
-                    ybuf[cur ^ 1][(mb * 3 + 1) * 64 + lane] = ystage.m;
-                    ybuf[cur ^ 1][(mb * 3 + 2) * 64 + lane] = ystage.l;
+                xs = make_x(ch + 1, (i + 1) % XA);
+                if (NB == 4 || mb < NB) {
+                    Split3& yn = yst[(i + 1) % XA];             // chunk ch + 1, requested XA chunks ago
+                    ybuf[cur ^ 1][(mb * 3 + 0) * 64 + lane] = yn.h;
+                    ybuf[cur ^ 1][(mb * 3 + 1) * 64 + lane] = yn.m;
+                    ybuf[cur ^ 1][(mb * 3 + 2) * 64 + lane] = yn.l;
+                    yn = sfrag_load(d.ysplit, min(ch + 1 + XA, ch_last), NB, mb, lane);
                 }
                 __syncthreads();
                 ++it;
             }
         }
-    }
+    };
+    if (fly) run(std::true_type{});
+    else run(std::false_type{});
     const int slab = d.slabs > 1 ? (int)((unsigned)range % (unsigned)d.slabs) : 0;
     float* __restrict__ Cs = d.C + (size_t)slab * d.slab_stride;
 #pragma unroll
