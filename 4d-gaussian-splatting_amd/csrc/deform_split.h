@@ -1192,6 +1192,25 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
         for (int fb = 0; fb < 4; ++fb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) c2[ob][fb][r] = 0.0f;
+    // product 1, K = 128 input features; both operands arrive as ready pieces (1 KiB coalesced loads)
+    // the relu(hidden) pieces are unique to the tile (HBM latency): requested HS_AHEAD K chunks ahead
+    constexpr int HS_AHEAD = 3;
+    constexpr int FA = FDGS_W2_FRAG_AHEAD;     // weight fragments requested FA steps ahead
+    Split3 f[FA + 1], hs[HS_AHEAD + 1][2];
+    // The first pieces of a (tile, head) step are requested during the second product of the step before it (and
+    // here for the first one): a wave has its SIMD to itself, and loads consumed right behind their request cost it
+    // a memory latency at the head of every step.
+    auto request_first = [&](int tile, int head) {
+        const u32x4* pwn = sel5(a.pw1n, head);
+#pragma unroll
+        for (int t = 0; t < FA; ++t) f[t] = sfrag_load_u(pwn, (t & 3) * 8 + (t >> 2), lane);
+#pragma unroll
+        for (int jj = 0; jj < HS_AHEAD; ++jj)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                hs[jj][mb] = sfrag_load_u(a.hsplit, min(tile * 2 + mb, ngroups - 1) * 8 + jj, lane);
+    };
+    request_first(t_begin, head_first);
     for (int tile = t_begin; tile < t_end; ++tile) {
         const int p0 = tile * 64;
         int G[2];
@@ -1213,17 +1232,6 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c1[mb][fb][r] = bias;
             }
-            // product 1, K = 128 input features; both operands arrive as ready pieces (1 KiB coalesced loads)
-            // the relu(hidden) pieces are unique to the tile (HBM latency): requested HS_AHEAD K chunks ahead
-            constexpr int HS_AHEAD = 3;
-            constexpr int FA = FDGS_W2_FRAG_AHEAD;     // weight fragments requested FA steps ahead
-            Split3 f[FA + 1], hs[HS_AHEAD + 1][2];
-#pragma unroll
-            for (int t = 0; t < FA; ++t) f[t] = sfrag_load_u(pw, (t & 3) * 8 + (t >> 2), lane);
-#pragma unroll
-            for (int jj = 0; jj < HS_AHEAD; ++jj)
-#pragma unroll
-                for (int mb = 0; mb < 2; ++mb) hs[jj][mb] = sfrag_load_u(a.hsplit, G[mb] * 8 + jj, lane);
 #pragma unroll
             for (int t = 0; t < 32; ++t) {
                 const int j = t >> 2, fb = t & 3;
@@ -1251,6 +1259,12 @@ deform_wgrad2_split_kernel(WGrad2SK a) {
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) c1[mb][fb] = mma_split(hs[j % (HS_AHEAD + 1)][mb], f[t % (FA + 1)], c1[mb][fb]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            {   // the step after this one (the last one of the wave repeats itself: a few unused loads)
+                const bool more_heads = head < head_last;
+                const int tile_n = more_heads ? tile : min(tile + 1, t_end - 1);
+                const int head_n = more_heads ? head + 1 : (tile + 1 < t_end ? head_first : head);
+                request_first(tile_n, head_n);
             }
             // product 2, K = the 64 points of this step: chunk (mb, jj) = points p0 + 32 mb + drow(8 jj + e, g)
 #pragma unroll
