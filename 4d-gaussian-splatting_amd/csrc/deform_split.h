@@ -785,14 +785,18 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
                 for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) t[cb][nb][r] = 0.0f;
+            // the twelve W2^T fragments, requested three steps ahead (a fragment consumed right behind its request
+            // costs this wave - alone on its SIMD - one L2 latency per step)
+            Split3 wq[4];
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) wq[i] = sfrag_load(a.pw2t_shs, i & 3, 3, i >> 2, lane);
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb) {
-                    const Split3 w = sfrag_load(a.pw2t_shs, nb, 3, j, lane);
+            for (int i = 0; i < 12; ++i) {
+                const int j = i >> 2, nb = i & 3;
+                if (i + 3 < 12) wq[(i + 3) & 3] = sfrag_load(a.pw2t_shs, (i + 3) & 3, 3, (i + 3) >> 2, lane);
 #pragma unroll
-                    for (int cb = 0; cb < SCB; ++cb) t[cb][nb] = mma_split(w, gsp[cb][j], t[cb][nb]);
-                }
+                for (int cb = 0; cb < SCB; ++cb) t[cb][nb] = mma_split(wq[i & 3], gsp[cb][j], t[cb][nb]);
+            }
         }
         // ReLU mask, and dh1 out
 #pragma unroll
