@@ -615,7 +615,11 @@ deform_fwd_split_kernel(DeformFwdSK a) {
             for (int cb = 0; cb < SCB; ++cb) {
                 const int p = min(base + 32 * cb + c, a.n - 1);
 #pragma unroll
-                for (int o = 0; o < 4; ++o) iv[cb][o] = o < k ? in[(size_t)p * k + o] + b2[o] : 0.0f;
+                for (int o = 0; o < 4; ++o) {    // unconditional loads (clamped index), then the select: see below
+                    const int oc = min(o, k - 1);
+                    const float v = in[(size_t)p * k + oc] + b2[oc];
+                    iv[cb][o] = o < k ? v : 0.0f;
+                }
             }
             save_act();
             small_head(w2s[head], k, h, h1, res);
@@ -635,13 +639,30 @@ deform_fwd_split_kernel(DeformFwdSK a) {
                 const int p = min(base + 32 * cb + c, a.n - 1);
                 const float* __restrict__ row0 = a.in_rest ? a.in_rest + (size_t)p * 45 - 3 : in + (size_t)p * k;
                 const float* __restrict__ dc = a.in_rest ? in + (size_t)p * 3 : nullptr;
+                // The residual inputs are requested here and used after the second layer.  Every load is
+                // unconditional: a load inside a branch (a lane-dependent one included) makes the compiler wait for
+                // ALL outstanding loads at the join, and the twelve requests of a point then go out one memory
+                // latency apart on a wave that has its SIMD to itself.  Which of the 8-row groups exist (48 rows) is
+                // known at compile time; the first group of the two-tensor layout takes its first three floats from
+                // the dc tensor by a select on the lane half.
 #pragma unroll
                 for (int ob = 0; ob < 2; ++ob)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+                        if (32 * ob + 8 * q >= 48) {
+                            iv[cb][ob][q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            continue;
+                        }
                         const int row = 32 * ob + 8 * q + 4 * h;
-                        iv[cb][ob][q] = row < k ? fdgs_load_sh4(row0, (ob == 0 && q == 0) ? dc : nullptr, row)
-                                                : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        if (ob == 0 && q == 0) {
+                            const fdgs_f4u hi = *reinterpret_cast<const fdgs_f4u*>(row0 + 4);
+                            const float* __restrict__ first = dc ? dc : row0;
+                            const float f0 = first[0], f1 = first[1], f2 = first[2], f3 = row0[3];
+                            iv[cb][ob][q] = h ? make_float4(hi.x, hi.y, hi.z, hi.w) : make_float4(f0, f1, f2, f3);
+                        } else {
+                            const fdgs_f4u v = *reinterpret_cast<const fdgs_f4u*>(row0 + row);
+                            iv[cb][ob][q] = make_float4(v.x, v.y, v.z, v.w);
+                        }
                     }
             }
             floatx16 o[SCB][2];
