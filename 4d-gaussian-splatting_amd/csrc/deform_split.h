@@ -454,6 +454,27 @@ __device__ __forceinline__ void relu_mask_apply(uint2 m, floatx16* x) {
 // Forward, kernel 2: the MLP.  One wave = 64 points (two column blocks), whole
 // register file, no LDS.
 // ---------------------------------------------------------------------------
+// The last-layer rows of the four heads with few outputs (3 + 3 + 4 + 1 rows of 128 floats) into LDS: all eight
+// 16-byte loads of a lane are requested before the first is stored (a copy loop goes load, wait, store, and a wave
+// that has its SIMD to itself pays one memory latency per trip).
+__device__ __forceinline__ void stage_small_w2(const float* const* w2, float (*w2s)[4 * DW], int lane) {
+    float4 v[4][2];
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        const int vecs = head_dim(hd) * (DW / 4);
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(sel5(w2, hd));
+#pragma unroll
+        for (int it = 0; it < 2; ++it) v[hd][it] = src[min(lane + 64 * it, vecs - 1)];
+    }
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+        const int vecs = head_dim(hd) * (DW / 4);
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            if (lane + 64 * it < vecs) reinterpret_cast<float4*>(w2s[hd])[lane + 64 * it] = v[hd][it];
+    }
+}
+
 struct DeformFwdSK {
     int n;
     const u32x4* feat_split;
@@ -502,13 +523,7 @@ deform_fwd_split_kernel(DeformFwdSK a) {
 
     // output layers of the four small heads (3+3+4+1 rows of 128) staged in LDS, one row group per head
     __shared__ float w2s[4][4 * DW];
-#pragma unroll
-    for (int hd = 0; hd < 4; ++hd) {
-        const int kk = head_dim(hd);
-        const float* src = sel5(a.w2, hd);
-        for (int i = lane; i < kk * (DW / 4); i += 64)
-            reinterpret_cast<float4*>(w2s[hd])[i] = reinterpret_cast<const float4*>(src)[i];
-    }
+    stage_small_w2(a.w2, w2s, lane);
     __syncthreads();
     floatx16 hid[SCB][4];
     split_first_linear(a.feat_split, a.pw0, a.pb0, blockIdx.x * SCB, (a.n + 31) / 32, lane, h, hid);
@@ -720,13 +735,7 @@ deform_bwd_points_split_kernel(DeformBwdSK a) {
     __shared__ float w2s[4][4 * DW];
     const int lane = threadIdx.x;
     const int c = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int hd = 0; hd < 4; ++hd) {
-        const int kk = head_dim(hd);
-        const float* src = sel5(a.w2, hd);
-        for (int i = lane; i < kk * (DW / 4); i += 64)
-            reinterpret_cast<float4*>(w2s[hd])[i] = reinterpret_cast<const float4*>(src)[i];
-    }
+    stage_small_w2(a.w2, w2s, lane);
     __syncthreads();
 
     int p[SCB], pc[SCB]; bool pvalid[SCB];
