@@ -1027,17 +1027,22 @@ deform_wgrad_split_kernel(WGradSK a) {
     auto run = [&](auto fly_c) {
         constexpr bool FLY = decltype(fly_c)::value;
         float cotr[XA];
-        unsigned mskr[XA];
+        uint2 mskr[XA];
         float xr[XA][8];
-        auto load_fly = [&](int ch, float& co, unsigned& mo) {
+        // the request keeps the words as they arrive; what is valid is decided where they are used, XA chunks later
+        // (a select at the request would wait for the load at once)
+        const long long cot_last = (long long)a.n * d.k - 1, msk_last = 2ll * a.n - 1;
+        auto load_fly = [&](int ch, float& cv, uint2& mv) {
             const int pb = min(ch, ch_last) * 16;
-            const long long cot_last = (long long)a.n * d.k - 1, msk_last = 2ll * a.n - 1;
             const long long ci = (long long)pb * d.k + lane, mi = (long long)pb * 2 + lane;
-            const float cv = d.cot[ci < cot_last ? ci : cot_last];
-            const uint2 m = d.mask[mi < msk_last ? mi : msk_last];
+            cv = d.cot[ci < cot_last ? ci : cot_last];
+            mv = d.mask[mi < msk_last ? mi : msk_last];
+        };
+        auto use_fly = [&](int ch, float cv, uint2 mv, float& co, unsigned& mo) {
             const bool real = ch <= ch_last;
+            const long long ci = (long long)ch * 16 * d.k + lane, mi = (long long)ch * 32 + lane;
             co = (real && lane < 16 * d.k && ci <= cot_last) ? cv : 0.0f;
-            mo = (real && lane < 32 && mi <= msk_last) ? ((mb >> 1) ? m.y : m.x) : 0u;
+            mo = (real && lane < 32 && mi <= msk_last) ? ((mb >> 1) ? mv.y : mv.x) : 0u;
         };
         auto load_x = [&](int ch, float* xo) {
             const int pb = min(ch, ch_last) * 16;
@@ -1090,8 +1095,11 @@ deform_wgrad_split_kernel(WGradSK a) {
         auto make_x = [&](int ch, int i) -> Split3 {
             float xv[8];
             if constexpr (FLY) {
-                fly_cot[mb][cot_slot] = cotr[i];
-                if (lane < 32) fly_msk[mb][msk_slot] = mskr[i];
+                float co;
+                unsigned mo;
+                use_fly(ch, cotr[i], mskr[i], co, mo);
+                fly_cot[mb][cot_slot] = co;
+                if (lane < 32) fly_msk[mb][msk_slot] = mo;
                 load_fly(ch + XA, cotr[i], mskr[i]);
                 if (d.k == 4) fly_x(std::integral_constant<int, 4>{}, xv);
                 else if (d.k == 3) fly_x(std::integral_constant<int, 3>{}, xv);
