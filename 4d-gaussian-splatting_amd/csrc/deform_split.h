@@ -998,11 +998,15 @@ deform_wgrad_split_kernel(WGradSK a) {
     __shared__ __align__(16) float fly_cot[4][64];
     __shared__ __align__(16) unsigned fly_msk[4][32];
     const bool fly = d.cot != nullptr;
-    float w2v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    // four scalars, not an array: captured by the loop's lambdas an array stayed in scratch memory, and its reload
+    // in every chunk - a vector-memory operation, the youngest one - made the wave wait for every prefetch in flight
+    float w2v0 = 0.0f, w2v1 = 0.0f, w2v2 = 0.0f, w2v3 = 0.0f;
     if (fly) {                                   // w2 == NULL: unit weights (X = mask * cot, k = 1)
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (o < d.k) w2v[o] = d.w2 ? d.w2[o * DW + 32 * mb + c] : 1.0f;
+        const float* __restrict__ wsrc = d.w2 ? d.w2 + 32 * mb + c : nullptr;
+        if (0 < d.k) w2v0 = wsrc ? wsrc[0 * DW] : 1.0f;
+        if (1 < d.k) w2v1 = wsrc ? wsrc[1 * DW] : 1.0f;
+        if (2 < d.k) w2v2 = wsrc ? wsrc[2 * DW] : 1.0f;
+        if (3 < d.k) w2v3 = wsrc ? wsrc[3 * DW] : 1.0f;
     }
     // feature 32 mb + c sits in the mask of lane half (c >> 2) & 1, word mb >> 1, at bit 31 - (16 (mb & 1) + r)
     // with r = (c & 3) + 4 ((c >> 3) & 3)
@@ -1081,8 +1085,9 @@ deform_wgrad_split_kernel(WGradSK a) {
             for (int o = 0; o < K; ++o) {
                 const float4 lo = cq[4 * o], hi = cq[4 * o + 1];
                 const float cv[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const float wo = o == 0 ? w2v0 : o == 1 ? w2v1 : o == 2 ? w2v2 : w2v3;     // o is a compile-time index
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = fmaf(w2v[o], cv[e], x[e]);
+                for (int e = 0; e < 8; ++e) x[e] = fmaf(wo, cv[e], x[e]);
             }
             const uint4 mlo = mq[0], mhi = mq[1];
             const unsigned mw[8] = {mlo.x, mlo.y, mlo.z, mlo.w, mhi.x, mhi.y, mhi.z, mhi.w};
