@@ -153,18 +153,30 @@ hexplane_bwd_brick_kernel(HexBrickK k, int lds_floats) {
     // window origin per level and axis, LDS offsets of the windows: per level three spatial planes
     // (ci = 0, 1, 3) as [tw_b][tw_a][16] and, with one shared time stamp, three time planes (ci = 2, 4, 5)
     // as [tw_a][16]
-    int lo[2][3], base[2][6];
+    // Window origins per level and axis as named scalars, not an array: `h ? lo[1][i] : lo[0][i]` is turned into a
+    // load through a selected pointer, i.e. a dynamic index, and the array then lives in scratch memory (a memory load
+    // per use inside the point loop).
+    int lo00, lo01, lo02, lo10, lo11, lo12;
+    int base0[6], base1[6];
+    auto lo_at = [&](bool upper, int ax) -> int {      // ax is a compile-time value at every call
+        const int v0 = ax == 0 ? lo00 : ax == 1 ? lo01 : lo02, v1 = ax == 0 ? lo10 : ax == 1 ? lo11 : lo12;
+        return upper ? v1 : v0;
+    };
     {
         const int bk[3] = {brick % k.nb[0], (brick / k.nb[0]) % k.nb[1], brick / (k.nb[0] * k.nb[1])};
         int off = 0;
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
 #pragma unroll
-            for (int ax = 0; ax < 3; ++ax) lo[l][ax] = (bk[ax] * (a.ps.res[l][ax] - 1)) / k.nb[ax];
+            for (int ax = 0; ax < 3; ++ax) {
+                const int v = (bk[ax] * (a.ps.res[l][ax] - 1)) / k.nb[ax];
+                if (l == 0) { if (ax == 0) lo00 = v; else if (ax == 1) lo01 = v; else lo02 = v; }
+                else { if (ax == 0) lo10 = v; else if (ax == 1) lo11 = v; else lo12 = v; }
+            }
 #pragma unroll
             for (int ci = 0; ci < 6; ++ci) {
                 const int ax = plane_a(ci), bx = plane_b(ci);
-                base[l][ci] = off;
+                if (l) base1[ci] = off; else base0[ci] = off;
                 if (bx < 3) off += k.tw[l][ax] * k.tw[l][bx] * DF;
                 else if (a.lds_time) off += k.tw[l][ax] * DF;
             }
@@ -250,19 +262,19 @@ hexplane_bwd_brick_kernel(HexBrickK k, int lds_floats) {
                 const float fx = axl[ax].f, fy = axl[bx].f;
                 const int dx = axl[ax].d, dy = axl[bx].d;
                 const int twa = h ? k.tw[1][ax] : k.tw[0][ax];
-                const int lx = axl[ax].i0 - (h ? lo[1][ax] : lo[0][ax]);
+                const int lx = axl[ax].i0 - lo_at(h != 0, ax);
                 bool in_lds = lx >= 0 && lx + dx < twa;
                 int cell = lx;
                 if (bx < 3) {
                     const int twb = h ? k.tw[1][bx] : k.tw[0][bx];
-                    const int ly = axl[bx].i0 - (h ? lo[1][bx] : lo[0][bx]);
+                    const int ly = axl[bx].i0 - lo_at(h != 0, bx);
                     in_lds = in_lds && ly >= 0 && ly + dy < twb;
                     cell += ly * twa;
                 } else {
                     in_lds = in_lds && a.lds_time;
                 }
                 if (in_lds) {
-                    double* L = lds + (h ? base[1][ci] : base[0][ci]) + cell * DF + ch;
+                    double* L = lds + (h ? base1[ci] : base0[ci]) + cell * DF + ch;
                     if (bx < 3) {
                         atomicAdd(L, (double)(g * ((1.0f - fx) * (1.0f - fy))));
                         atomicAdd(L + dx * DF, (double)(g * (fx * (1.0f - fy))));
@@ -307,7 +319,7 @@ hexplane_bwd_brick_kernel(HexBrickK k, int lds_floats) {
             const int twa = k.tw[l][ax], Wd = a.ps.res[l][ax];
             const int rows = bx < 3 ? k.tw[l][bx] : 1;
             const int count = rows * twa * DF;
-            const double* L = lds + base[l][ci];
+            const double* L = lds + (l ? base1[ci] : base0[ci]);
             float* gp = a.gpl[l][ci];
             for (int i = threadIdx.x; i < count; i += BRICK_THREADS) {
                 const double val = L[i];
@@ -315,10 +327,10 @@ hexplane_bwd_brick_kernel(HexBrickK k, int lds_floats) {
                     const int t = i >> 4, c = i & 15;
                     const int ly = t / twa, lx = t - ly * twa;
                     if (bx < 3) {
-                        atomicAdd(gp + ((size_t)(lo[l][bx] + ly) * Wd + lo[l][ax] + lx) * DF + c, (float)val);
+                        atomicAdd(gp + ((size_t)(lo_at(l != 0, bx) + ly) * Wd + lo_at(l != 0, ax) + lx) * DF + c, (float)val);
                     } else {
-                        atomicAdd(gp + ((size_t)ty0 * Wd + lo[l][ax] + lx) * DF + c, (float)(val * (1.0 - ft)));
-                        atomicAdd(gp + ((size_t)ty1 * Wd + lo[l][ax] + lx) * DF + c, (float)(val * ft));
+                        atomicAdd(gp + ((size_t)ty0 * Wd + lo_at(l != 0, ax) + lx) * DF + c, (float)(val * (1.0 - ft)));
+                        atomicAdd(gp + ((size_t)ty1 * Wd + lo_at(l != 0, ax) + lx) * DF + c, (float)(val * ft));
                     }
                 }
             }
