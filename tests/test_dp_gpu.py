@@ -19,10 +19,10 @@ def _same_to_rounding(got, ref, name):
     tensor's largest magnitude (typically 2e-7).  Measured on this test: in about one two-rank run in six a few single
     elements of the Gaussians' gradients (positions, SH) differ from the one-rank run by up to 8e-4 of that magnitude -
     with the radix sort or the tile-binned one, one stream or two in the deformation backward, block verdicts from
-    the forward or recomputed, and with builds from before those existed; eight pairs of identical one-rank runs
-    showed none.  The cause is not established (rounding noise amplified by a nearly degenerate 2-D covariance is the
-    candidate; a timing-dependent ordering bug that only two processes on one GPU expose is not excluded).  Until it
-    is, the bound holds for all but one element in a thousand, and 5e-3 for those."""
+    the forward or recomputed, and with builds from before those existed; 28 pairs of identical one-rank runs
+    showed none, so it is not the atomics' rounding noise alone.  The cause is not established (something in the
+    two-process rehearsal - two processes sharing the GPU, the exchange staged through host memory - varies from run
+    to run).  Until it is, the bound holds for all but one element in a thousand, and 5e-3 for those."""
     ref = ref.float()
     diff = (got.float() - ref).abs().flatten()
     scale = float(ref.abs().max())
