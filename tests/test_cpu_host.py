@@ -212,3 +212,25 @@ def test_ctypes_structures_match_the_header(tmp_path):
         assert int(value) == want, (cls, field, int(value), want)
         seen += 1
     assert seen == sum(1 + len(getattr(_lib, c)._fields_) for c in pairs)
+
+
+def test_library_has_no_packed_fp32_arithmetic():
+    """The built library's gfx950 code holds no packed fp32 instruction (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32,
+    v_pk_mov_b32): csrc/Makefile switches both vectorizers off because such instructions returned wrong low halves
+    in lanes 48-63 when a wave issuing bf16 matrix instructions shared the compute unit (tools/share_probe.sh).  A
+    flag dropped from one translation unit, or vector arithmetic written by hand, fails here."""
+    import importlib.util
+    import shutil
+    spec = importlib.util.spec_from_file_location("isa_scan", os.path.join(ROOT, "tools", "isa_scan.py"))
+    isa_scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(isa_scan)
+    if not os.path.exists(isa_scan.OBJDUMP) and shutil.which("llvm-objdump") is None:
+        pytest.skip("no llvm-objdump")
+    from fdgs import _lib
+    per = isa_scan.disassemble(_lib.LIB_PATH)
+    kernels = [k for k in per if "kernel" in k]
+    assert len(kernels) > 40, "the disassembly did not find the library's kernels"
+    packed = {k: sorted({o for o in ops if o.startswith("v_pk_") and (o.endswith("_f32") or o == "v_pk_mov_b32")})
+              for k, ops in per.items()}
+    packed = {k: v for k, v in packed.items() if v}
+    assert not packed, packed

@@ -16,9 +16,8 @@ TMP=$(mktemp -d)
 EXTRA=""
 case "$SRC" in
   raster_preprocess.hip) EXTRA="-ffp-contract=off" ;;
-  raster_blend.hip) EXTRA="-fno-slp-vectorize" ;;
 esac
-(cd "$TMP" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics $EXTRA \
+(cd "$TMP" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize -fno-vectorize $EXTRA \
     -I"$ROOT/include" -I"$CS" --save-temps -c "$CS/$SRC" -o x.o 2>/dev/null)
 ASM=$(ls "$TMP"/*-hip-amdgcn-amd-amdhsa-gfx950.s)
 python3 - "$ASM" <<'PY'
