@@ -234,3 +234,26 @@ def test_library_has_no_packed_fp32_arithmetic():
               for k, ops in per.items()}
     packed = {k: v for k, v in packed.items() if v}
     assert not packed, packed
+
+
+def test_integration_document_matches_header_and_abi():
+    """INTEGRATION.md's ctypes example is the output of tools/gen_integration_stub.py for the current header (a reader
+    who copies it passes a structure of the right length), the structure it defines has the binding's own layout,
+    and every ABI number the document quotes is the library's."""
+    import ctypes
+    import subprocess
+    import sys
+    from fdgs import _lib
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_integration_stub.py"), "--check"])
+    assert r.returncode == 0, "INTEGRATION.md is stale: run python tools/gen_integration_stub.py"
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    quoted = [int(v) for v in re.findall(r"fdgs_abi_version\(\)`? (?:is|==) (\d+)", doc)]
+    assert quoted and all(v == _lib.lib.fdgs_abi_version() for v in quoted), quoted
+    block = doc[doc.index("class BlendFwdArgs(C.Structure)"):]
+    block = block[:block.index("\n\n")]
+    scope = {"C": ctypes}
+    exec(block, scope)
+    mine, theirs = scope["BlendFwdArgs"], _lib.BlendFwdArgs
+    assert [f for f, _ in mine._fields_] == [f for f, _ in theirs._fields_]
+    assert ctypes.sizeof(mine) == ctypes.sizeof(theirs)
+    assert all(getattr(mine, f).offset == getattr(theirs, f).offset for f, _ in mine._fields_)
