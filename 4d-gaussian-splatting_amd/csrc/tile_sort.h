@@ -492,6 +492,8 @@ __device__ __forceinline__ void ts_sort_words(uint32_t* __restrict__ w, int lp) 
     }
 }
 
+#define TS_TIE_RUN_MAX 48                           // longest run of equal depth fields ranked pairwise (see tile_sort_kernel)
+
 // The same network on n distinct 64-bit numbers s[0, n) where they lie (in memory: segments longer than any LDS
 // segment): the positions n .. P-1 of the padded problem would hold +infinity and are never written, a comparator
 // that reaches them is skipped.
@@ -533,6 +535,7 @@ tile_sort_kernel(uint64_t* __restrict__ binned, const uint4* __restrict__ desc, 
     constexpr int ITEMS = CAP / THREADS;
     __shared__ uint32_t word[TS_WORDS(CAP)];
     __shared__ uint32_t s_lo, s_hi;
+    __shared__ int s_run;                           // 1 when a run of equal depth fields is longer than TS_TIE_RUN_MAX
     for (int w = blockIdx.x; w < tiles; w += gridDim.x) {
         const uint4 d4 = desc[w];
         const uint32_t tile = d4.x, first = d4.y;
@@ -557,7 +560,7 @@ tile_sort_kernel(uint64_t* __restrict__ binned, const uint4* __restrict__ desc, 
             }
             continue;
         }
-        if (threadIdx.x == 0) { s_lo = 0xffffffffu; s_hi = 0u; }
+        if (threadIdx.x == 0) { s_lo = 0xffffffffu; s_hi = 0u; s_run = 0; }
         __syncthreads();
         uint32_t dv[ITEMS];
         uint32_t dlo = 0xffffffffu, dhi = 0u;
@@ -591,6 +594,30 @@ tile_sort_kernel(uint64_t* __restrict__ binned, const uint4* __restrict__ desc, 
         ts_sort_words<THREADS>(word, lp);
         __syncthreads();
         const uint32_t imask = (uint32_t)P - 1u;
+        // The exact order among entries of one depth field is restored below by ranking every tied entry inside its
+        // run: quadratic in the run length.  A segment with a run of more than TS_TIE_RUN_MAX entries (coincident or
+        // duplicated Gaussians, a depth span far narrower than the field) is sorted by the 64-bit network on the
+        // full numbers instead, where it lies in memory; the first entry of each run looks that far ahead, no further.
+        for (int p = threadIdx.x; p < n; p += THREADS) {
+            const uint32_t field = word[ts_pa(p)] >> lp;
+            if (p == 0 || (word[ts_pa(p - 1)] >> lp) != field) {
+                int b = p + 1;
+                while (b < n && b - p <= TS_TIE_RUN_MAX && (word[ts_pa(b)] >> lp) == field) ++b;
+                if (b - p > TS_TIE_RUN_MAX) s_run = 1;
+            }
+        }
+        __syncthreads();
+        if (s_run) {
+            uint64_t* seg = binned + first;
+            ts_bitonic64<THREADS>(seg, n, P);
+            for (int i = threadIdx.x; i < n; i += THREADS) {
+                const uint64_t e = seg[i];
+                keys_out[first + i] = hi | (e >> 32);
+                vals_out[first + i] = (uint32_t)e;
+            }
+            __syncthreads();
+            continue;
+        }
         for (int p = threadIdx.x; p < n; p += THREADS) {
             const uint32_t wd = word[ts_pa(p)], field = wd >> lp;
             const uint64_t e = binned[first + (wd & imask)];

@@ -118,9 +118,13 @@ static __device__ __align__(256) float scratch[2 * FDGS_L1_STATIC_MAX_PARTIALS];
 static std::mutex scratch_mu;
 static float* scratch_ptr[L1_MAX_DEVICES];        // device address of `scratch` on each device, 0 until looked up
 
-static int scratch_address(float** out) {
+// The array that belongs to the CURRENT device: hipGetSymbolAddress answers for that one.  A stream of another
+// device is refused (its kernels would receive the current device's address).
+static int scratch_address(hipStream_t s, float** out) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= L1_MAX_DEVICES) return FDGS_ELAUNCH;
+    hipDevice_t sdev = -1;
+    if (s && hipStreamGetDevice(s, &sdev) == hipSuccess && (int)sdev != dev) return FDGS_EINVAL;
     std::lock_guard<std::mutex> lock(scratch_mu);
     if (!scratch_ptr[dev]) {
         float* p = nullptr;
@@ -138,9 +142,9 @@ extern "C" int fdgs_l1_loss_fwd_static(const fdgs_l1_fwd_args* a, void* stream) 
     const size_t blocks = fdgs_l1_loss_partials(a->n);          // <= FDGS_L1_STATIC_MAX_PARTIALS by the check above
     if (blocks > FDGS_L1_STATIC_MAX_PARTIALS) return FDGS_ETOOLARGE;
     fdgs_l1_fwd_args k = *a;
-    int rc = scratch_address(&k.partial);
-    if (rc != FDGS_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    int rc = scratch_address(s, &k.partial);
+    if (rc != FDGS_OK) return rc;
     hipLaunchKernelGGL(l1_partial_kernel, dim3((unsigned)blocks), dim3(L1_THREADS), 0, s, k);
     FDGS_CHECK_LAUNCH();
     hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(L1_THREADS), 0, s, k, (int)blocks);

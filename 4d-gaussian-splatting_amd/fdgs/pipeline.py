@@ -288,7 +288,11 @@ class ViewPipeline:
                 else:
                     buf = own.clone()        # the kernels below still read this view's own blocks as cotangents
                 pending = early_hook(buf, self.radii)
-                early = self.early_views(buf)
+                # With grad_set 0 and no collective started (the hook returned None) the copy is dropped: the view's
+                # own blocks stay the gradients and travel with the arena afterwards.  With grad_set 1 the range has
+                # been added to set 0's in any case, and that sum is what the caller continues with.
+                if pending is not None or grad_set != 0:
+                    early = self.early_views(buf)
             G = _deformation._fill_params(net, deform_grads)
             b = _lib.DeformBwdArgs(N, P, ptr(xyz), None, float(cam.time), None if split else ptr(self.hidden),
                                    ptr(self.act) if split else None, ptr(self.mask) if split else None,

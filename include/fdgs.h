@@ -384,7 +384,10 @@ int fdgs_l1_loss_bwd(const fdgs_l1_bwd_args* a, void* stream);
  * Limit: n <= FDGS_L1_STATIC_MAX_N, larger n returns FDGS_ETOOLARGE.  Calls no allocating routine; the first call
  * on a device looks the array's address up once (hipGetSymbolAddress) and keeps it.  Every call on a GPU shares that
  * GPU's array: calls that may overlap in time on one GPU (two streams, two threads) race and must be serialised by
- * the caller; nothing has to start at zero (every partial that is read was written by the same call).          */
+ * the caller; nothing has to start at zero (every partial that is read was written by the same call).
+ * The array used is the CURRENT device's: `stream` must belong to the current device (a stream of another device
+ * returns FDGS_EINVAL).  Under graph capture, make one call per device BEFORE the capture begins: the first call's
+ * address lookup takes a lock and calls hipGetSymbolAddress, which a capture need not permit.                  */
 #define FDGS_L1_STATIC_MAX_PARTIALS 16384
 #define FDGS_L1_STATIC_MAX_N ((int64_t)FDGS_L1_STATIC_MAX_PARTIALS * 4096)      /* 67,108,864 floats */
 int fdgs_l1_loss_fwd_static(const fdgs_l1_fwd_args* a, void* stream);

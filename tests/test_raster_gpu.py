@@ -76,7 +76,8 @@ def test_forward_stages(name, sort, monkeypatch):
     (10000, 64, 48, 8.0, 2500),      # ... with 2500 Gaussians at one depth (ranked by id inside their depth field)
     (30000, 32, 32, 8.0, 0),         # 4 tiles, lists beyond every LDS segment: sorted where they lie in memory
     (30000, 32, 32, 8.0, 9000),
-    (3000, 200, 120, 1.0, 700),      # short lists with ties
+    (3000, 200, 120, 1.0, 700),      # short lists with ties (runs longer than the pairwise ranking takes: 64-bit network)
+    (3000, 200, 120, 1.0, 20),       # ... with runs short enough to be ranked pairwise
     (3000, 3840, 2160, 12.0, 0),     # 32400 tiles: the walks' per-tile counters take 130 KB of LDS
     (3000, 2944, 2944, 12.0, 0),     # 33856 tiles, more than the counters hold: the call falls back to the radix sort
 ])
