@@ -19,6 +19,31 @@ from . import _lib, deformation as _deformation, rasterizer as _rasterizer
 from ._lib import lib, ptr
 
 
+def arena_layout(N, deform_numel):
+    """The flat gradient array of one set: (regions, marks, total floats).  Order
+        deformation field | xyz | means2D | scaling | rotation | opacity | shs        (each padded to 256 bytes)
+    marks[name] is a region's first float, marks["end"] the total."""
+    def pad(n):
+        return (n + 63) // 64 * 64
+    regions = (("dflat", (deform_numel,)), ("xyz", (N, 3)), ("means2D", (N, 3)), ("scaling", (N, 3)),
+               ("rotation", (N, 4)), ("opacity", (N, 1)), ("shs", (N, 16, 3)))
+    marks, off = {}, 0
+    for name, shape in regions:
+        marks[name] = off
+        off += pad(math.prod(shape))
+    marks["end"] = off
+    return regions, marks, off
+
+
+def exchange_bounds(marks, fine, early_done):
+    """[first, last) of the arena a data-parallel exchange still has to sum over the ranks: everything (fine stage),
+    everything but the deformation field (coarse stage: it has no gradient), and only up to the early range
+    (means2D .. shs) once that range has travelled by itself."""
+    first = marks["dflat"] if fine else marks["xyz"]
+    last = marks["means2D"] if early_done else marks["end"]
+    return first, last
+
+
 class ViewGrads:
     """Gradients of one view: per-Gaussian tensors (raw-parameter space) and the deformation field's flat buffer."""
     __slots__ = ("xyz", "scaling", "rotation", "opacity", "shs", "means2D", "radii", "loss", "psnr", "early_exchanged")
@@ -92,22 +117,14 @@ class ViewPipeline:
         # all of it; all but the deformation field (coarse stage); or in two parts - "early": means2D .. shs, final
         # once the rasterizer backward has run (these reach their parameters through the residual adds only), and
         # "late": deformation field + xyz, which the deformation backward produces.
-        def pad(n):
-            return (n + 63) // 64 * 64
-        D = self.deform_numel
-        regions = (("dflat", (D,)), ("xyz", (N, 3)), ("means2D", (N, 3)), ("scaling", (N, 3)), ("rotation", (N, 4)),
-                   ("opacity", (N, 1)), ("shs", (N, 16, 3)))
-        self.arena_regions = regions
-        self.sets, self.arenas, self.arena_marks = [], [], {}
+        regions, marks, total = arena_layout(N, self.deform_numel)
+        self.arena_regions, self.arena_marks = regions, marks
+        self.sets, self.arenas = [], []
         for _ in range(2):
-            total = sum(pad(math.prod(shape)) for _, shape in regions)
             arena = torch.zeros(total, device=dev, dtype=f32)
-            views, off = dict(means3D=e(N, 3)), 0
+            views = dict(means3D=e(N, 3))
             for name, shape in regions:
-                views[name] = arena[off:off + math.prod(shape)].view(shape)
-                self.arena_marks[name] = off
-                off += pad(math.prod(shape))
-            self.arena_marks["end"] = off
+                views[name] = arena[marks[name]:marks[name] + math.prod(shape)].view(shape)
             self.sets.append(views)
             self.arenas.append(arena)
         self._one = torch.ones(1, device=dev, dtype=f32)
@@ -117,9 +134,7 @@ class ViewPipeline:
 
     def exchange_range(self, fine, early_done):
         """The part of set 0's arena a data-parallel exchange still has to sum over the ranks: a 1-D view."""
-        m = self.arena_marks
-        first = m["dflat"] if fine else m["xyz"]
-        last = m["means2D"] if early_done else m["end"]
+        first, last = exchange_bounds(self.arena_marks, fine, early_done)
         return self.arenas[0][first:last]
 
     def early_views(self, buf):

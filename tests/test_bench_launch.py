@@ -45,3 +45,15 @@ def test_world_size_mismatch_is_an_error():
 def test_batch_not_divisible_is_an_error():
     r = _run("--gpus", "2", "--dry-run", "--global-batch", "3")
     assert r.returncode != 0
+
+
+def test_gpus_4_and_8_split_the_batch_of_eight():
+    """The launch lines of the scaling runs (N = 4, 8): N ranks come up, one JSON line, 2 and 1 views per rank."""
+    for n, per in ((4, 2), (8, 1)):
+        r = _run("--gpus", str(n), "--dry-run")
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == n and out["ranks_seen"] == n and out["scaling"] == "strong"
+        assert out["config"] == {"global_batch_views": 8, "views_per_gpu": per}

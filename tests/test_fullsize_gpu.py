@@ -250,3 +250,85 @@ def test_train_step_at_the_2m_stress_size():
     assert int((step.denom[:, 0] > 0).sum()) > n // 2 and float(step.denom.max()) == 1.0
     assert float(step.max_radii2D.max()) > 0 and float(step.xyz_gradient_accum.sum()) > 0
     assert not torch.equal(before, g._xyz.detach())
+
+
+def test_composed_render_against_both_oracles_at_300k():
+    """render() as a whole at the benchmark size (300k Gaussians, 1352x1014, fine stage): deformation field,
+    activations, rasterizer, and the backward pass through all of them down to the raw Gaussian parameters and the
+    34 tensors of the deformation field (src/gaussian_renderer/__init__.py:79-113 of the reference).  The loss lives on
+    42 sampled tiles.  The oracle side runs in two steps so that both see the same tile lists: the rasterizer oracle
+    on the GPU's deformation outputs (image <= 1e-5, and the cotangents of the five outputs), then the deformation
+    oracle's own forward (outputs <= 2e-5) and its backward from those cotangents (gradients <= 1e-4 of each
+    tensor's largest magnitude)."""
+    from fdgs.deformation import DeformationFields
+    from fdgs.renderer import render
+    from fdgs.train_step import DeformHolder
+    from oracle import deform_ref
+    dev = torch.device("cuda:0")
+    n = 300000
+    cam = ss.make_cameras(21, W, H, device=dev)[7]
+    t = float(cam.time)
+    g = ss.GaussianParams(n, device=dev)
+    torch.manual_seed(ss.SEED)
+    net = ss.perturb_deformation_(DeformationFields(ss.DYNERF_NET_KWARGS)).to(dev)
+    net.deformation_net.set_aabb(list(ss.SCENE_MAX), list(ss.SCENE_MIN))
+    bg = torch.ones(3, device=dev)
+    cpu_cam = ss.make_cameras(21, W, H)[7]
+    S = rr.Settings(H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), torch.ones(3), 1.0,
+                    cpu_cam.world_view_transform, cpu_cam.full_proj_transform, 3, cpu_cam.camera_center)
+    gx, gy = rr.tile_grid(S)
+    tiles = list(range(17, gx * gy, 131))
+    mask = torch.zeros(gy * 16, gx * 16, dtype=torch.bool)
+    for tl in tiles:
+        ty, tx = divmod(tl, gx)
+        mask[ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16] = True
+    mask = mask[:H, :W]
+    gout = torch.rand(3, H, W, generator=torch.Generator().manual_seed(11)) * mask
+
+    # the product path, as the trainer calls it
+    pkg = render(cam, g, DeformHolder(net), bg, stage="fine", cam_type="dynerf")
+    (pkg["render"] * gout.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    raw = [g._xyz, g._scaling, g._rotation, g._opacity, g._features_dc, g._features_rest]
+    got_raw = [p.grad.detach().cpu() for p in raw]
+    got_net = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.requires_grad}
+    assert len(got_net) == 34
+
+    # the GPU's deformation outputs (same kernels, same bits as inside render())
+    with torch.no_grad():
+        d_out = [o.cpu() for o in net(g._xyz, g._scaling, g._rotation, g._opacity, g.get_features, t)]
+
+    # step 1: rasterizer oracle on those outputs, activations as gaussian_renderer/__init__.py:85-87
+    o = [x.clone().requires_grad_(True) for x in d_out]
+    m2 = torch.zeros(n, 3, requires_grad=True)
+    color, radii, depth, aux = rr.rasterize(o[0], m2, o[4], torch.sigmoid(o[3]), torch.exp(o[1]),
+                                            torch.nn.functional.normalize(o[2]), S, tiles=tiles, return_aux=True)
+    (color * gout).sum().backward()
+    perr = ((pkg["render"].detach().cpu() - color.detach()).abs() * mask).amax(dim=0)
+    assert int((perr > 1e-5).sum()) <= 3 and float(perr.max()) <= 1.0 / 255.0, (int((perr > 1e-5).sum()), float(perr.max()))
+    assert torch.equal(pkg["radii"].cpu(), radii)
+    vs = pkg["viewspace_points"].grad.cpu()
+    assert float((vs - m2.grad).abs().max()) <= 1e-4 * float(m2.grad.abs().max())
+
+    # step 2: deformation oracle, forward and backward from the rasterizer oracle's cotangents
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and k in got_net)
+          for k, v in net.state_dict().items()}
+    feats = torch.cat((g._features_dc.detach().cpu(), g._features_rest.detach().cpu()), dim=1)
+    ins = [p.detach().cpu().clone().requires_grad_(True) for p in (g._xyz, g._scaling, g._rotation, g._opacity)]
+    ins.append(feats.clone().requires_grad_(True))
+    ref = deform_ref.deform_forward(sd, *ins, torch.full((n, 1), t))
+    for a, b in zip(d_out, ref):
+        assert float((a - b.detach()).abs().max()) <= 2e-5
+    torch.autograd.backward(list(ref), [x.grad for x in o])
+    ref_raw = [ins[0].grad, ins[1].grad, ins[2].grad, ins[3].grad, ins[4].grad[:, :1], ins[4].grad[:, 1:]]
+    names = ["xyz", "scaling", "rotation", "opacity", "features_dc", "features_rest"]
+    for name, a, b in zip(names, got_raw, ref_raw):
+        scale = float(b.abs().max()) + 1e-30
+        d = (a - b).abs().reshape(n, -1).amax(dim=1)
+        # a ReLU decision within rounding of zero flips between any two correct implementations and moves that one
+        # point's position gradient (the other five tensors bypass the network: residual adds)
+        assert int((d > 1e-4 * scale).sum()) <= (2 if name == "xyz" else 0), (name, float(d.max()) / scale)
+    for k, a in got_net.items():
+        b = sd[k].grad
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 1e-4 * scale, (k, float((a - b).abs().max()) / scale)
