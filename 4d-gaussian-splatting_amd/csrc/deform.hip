@@ -1209,7 +1209,26 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
             t.d[t.n++] = SFragDesc{a->p.w1[h], pk, DW, DW, DW, 0};
             pw1n[h] = pk; pk += sfrag_vec4(DW, DW);
         }
-        rc = launch_pack_split(t, s);
+        // Three clears ride in this launch (each took a launch of its own before): the private copies of the small
+        // accumulators (dW0 / db0, dW2 / db2, the opacity head's Q / T: contiguous), the channel-last plane
+        // gradients, and the brick histogram.  Everything that reads them is enqueued behind this launch, on this
+        // stream or behind a fork event recorded after it.
+        {
+            const size_t dw0_floats = (size_t)DW0_SLABS * (DW * 32 + DW);
+            float* slabs_first = ws_yfeat + (size_t)48 * ((size_t)n + 16);
+            const size_t slab_floats = dw0_floats + (size_t)W2_SLABS * W2_SLAB_FLOATS + DW * DW + DW;
+            static_assert(((size_t)DW0_SLABS * (DW * 32 + DW)) % 4 == 0 && ((size_t)W2_SLABS * W2_SLAB_FLOATS + DW * DW + DW) % 4 == 0,
+                          "the cleared regions are whole 16-byte words");
+            t.d[t.n++] = SFragDesc{nullptr, reinterpret_cast<u32x4*>(slabs_first), (int)(slab_floats / 4), 0, 0, FRAG_ZERO};
+            t.d[t.n++] = SFragDesc{nullptr, reinterpret_cast<u32x4*>(grads_cl), (int)(pf / 4), 0, 0, FRAG_ZERO};
+            int* brick_counts = ws_brick + n + (n + 1) / 2;
+            // the histogram starts at a 4-byte boundary only: clear from the 16-byte boundary below it (the words in
+            // between are the tail of brick_of, rewritten by brick_hist_kernel before anything reads them)
+            const size_t mis = ((size_t)brick_counts & 15) / 4;
+            t.d[t.n++] = SFragDesc{nullptr, reinterpret_cast<u32x4*>(brick_counts - mis), (int)((BRICK_MAX + mis + 3) / 4), 0, 0,
+                                   FRAG_ZERO};
+        }
+        rc = launch_pack_split(t, s, 64);
         if (rc != FDGS_OK) return rc;
         for (int h = 0; h < 5; ++h) ks.w2[h] = a->p.w2[h];
         ks.mask = reinterpret_cast<const uint2*>(a->mask);
@@ -1334,7 +1353,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     bool binned = false;
     auto brick_binning = [&](hipStream_t hs) -> int {
         const int nbr = bk.nb[0] * bk.nb[1] * bk.nb[2];
-        if (hipMemsetAsync(bb.counts, 0, (size_t)nbr * sizeof(int), hs) != hipSuccess) return FDGS_ELAUNCH;
+        if (!split && hipMemsetAsync(bb.counts, 0, (size_t)nbr * sizeof(int), hs) != hipSuccess) return FDGS_ELAUNCH;
         const int sort_blocks = (n + BRICK_SORT_PTS - 1) / BRICK_SORT_PTS;
         hipLaunchKernelGGL(brick_hist_kernel, dim3(sort_blocks), dim3(256), 0, hs, bb);
         FDGS_CHECK_LAUNCH();
@@ -1346,7 +1365,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
         return FDGS_OK;
     };
     // pass 1b + dW0 + plane-gradient layout change: everything downstream of dfeat; runs on stream hs
-    bool grads_cleared = false;
+    bool grads_cleared = split;          // split mode: cleared by the pack launch
     auto hex_tail = [&](hipStream_t hs) -> int {
         if (!grads_cleared && hipMemsetAsync(grads_cl, 0, pf * sizeof(float), hs) != hipSuccess) return FDGS_ELAUNCH;
         // HexPlane backward (plane scatter, coordinate gradient, features for dW0)
@@ -1434,14 +1453,7 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     // private copies of the small dW2 / db2 accumulators (split mode), folded into the outputs after the loop
     float* w2_slabs = ws_yfeat + (size_t)48 * ((size_t)n + 16) + (size_t)DW0_SLABS * (DW * 32 + DW);
     float* op_q = w2_slabs + (size_t)W2_SLABS * W2_SLAB_FLOATS;      // Q [128][128], then T [128]
-    {   // one clear for the dW2 / db2 copies and the opacity head's Q / T and, when the dW0 product runs on this
-        // stream (yfeat given), its copies, which lie right before them
-        const bool with_dw0 = split && a->yfeat;
-        const size_t dw0_floats = (size_t)DW0_SLABS * (DW * 32 + DW);
-        float* first = with_dw0 ? w2_slabs - dw0_floats : w2_slabs;
-        const size_t floats = (size_t)W2_SLABS * W2_SLAB_FLOATS + DW * DW + DW + (with_dw0 ? dw0_floats : 0);
-        if (split && hipMemsetAsync(first, 0, floats * sizeof(float), s) != hipSuccess) return FDGS_ELAUNCH;
-    }
+    // (split mode: these copies, the dW0 / db0 copies before them and Q / T behind them were cleared by the pack launch)
     // What depends on nothing of pass 1 goes to the side stream first and runs beside that pass (whose one wave per
     // SIMD leaves the last round of its launch partly idle): the binning of the points into bricks and the column
     // sums of the cotangents (db2), over all points at once.  FDGS_NO_EARLY_SIDE keeps the single fork after pass 1.
@@ -1450,7 +1462,8 @@ extern "C" int fdgs_deform_bwd(const fdgs_deform_bwd_args* a, void* stream) {
     if (early_side) {
         if (hipEventRecord(side->fork, s) != hipSuccess || hipStreamWaitEvent(side->stream, side->fork, 0) != hipSuccess)
             return FDGS_ELAUNCH;
-        if (hipMemsetAsync(grads_cl, 0, pf * sizeof(float), side->stream) != hipSuccess) return FDGS_ELAUNCH;
+        if (!grads_cleared && hipMemsetAsync(grads_cl, 0, pf * sizeof(float), side->stream) != hipSuccess)
+            return FDGS_ELAUNCH;
         grads_cleared = true;
         if (bricks) {
             rc = brick_binning(side->stream);

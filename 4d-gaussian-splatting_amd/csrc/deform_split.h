@@ -91,6 +91,7 @@ __device__ __forceinline__ floatx16 mma_split(const Split3& a, const Split3& b, 
 // ---------------------------------------------------------------------------
 #define FRAG_BIAS 8          // not a matrix: a bias vector, copied and zero-padded
 #define FRAG_PLANE 16        // not a matrix: a feature plane [16][I texels], rewritten channel-last [I][16]
+#define FRAG_ZERO 32         // not a matrix: I 16-byte words at dst are cleared (src unused; dst 16-byte aligned)
 struct SFragDesc { const float* src; u32x4* dst; int I; int K; int ld; int mode; };
 struct SFragTable { SFragDesc d[FRAG_MAX]; int n; };
 
@@ -113,6 +114,11 @@ pack_split_kernel(SFragTable t) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) q[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
         }
+        return;
+    }
+    if (d.mode & FRAG_ZERO) {            // a clear that rides in this launch instead of taking one of its own
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < d.I; idx += gridDim.x * blockDim.x) d.dst[idx] = z;
         return;
     }
     if (d.mode & FRAG_BIAS) {            // plain copy of I floats, zero-padded to K
