@@ -173,8 +173,9 @@ def _set_pointers(P, tensors, n_levels):
         k += 4
 
 
-def _fill_params(net, grads=None):
-    """fdgs_deform_params from the module's tensors, or the gradient twin from `grads` (same order)."""
+def _fill_params(net, grads=None, tensors=None):
+    """fdgs_deform_params from the module's tensors (or from `tensors`, the same 34 in the same order: the
+    zero-padded set of a narrower network), or the gradient twin from `grads` (same order)."""
     grid = net.grid
     n_levels = len(grid.resolutions)
     if grads is not None:
@@ -188,8 +189,31 @@ def _fill_params(net, grads=None):
             P.res[l][k] = int(reso[k])
     P.aabb = ptr(grid.aabb.detach())
     P.matmul = MATMUL
-    _set_pointers(P, _trainable(net), n_levels)
+    _set_pointers(P, _trainable(net) if tensors is None else tensors, n_levels)
     return P
+
+
+KERNEL_WIDTH = 128          # hidden width the kernels are built for
+
+
+def _kernel_parameters(net):
+    """The 34 tensors as the kernels take them.  A network narrower than 128 (configs/train/dnerf.yaml:83 has
+    net_width 64; create_net, src/model/deformation.py:62-81, builds any width) runs as the 128-wide network whose
+    extra hidden units have zero weights and zero biases: those units are exactly zero before and after every ReLU,
+    the products they enter are exact zeros, and every sum only gains zeros - the outputs are those of the narrow
+    network, and so are the gradients of its own entries (the padding's gradients are dropped by the slicing that
+    autograd does for F.pad).  Costs the flops of the wide network."""
+    ts = _trainable(net)
+    pad = KERNEL_WIDTH - net.W
+    if pad == 0:
+        return ts
+    F = torch.nn.functional
+    out = list(ts[:12])
+    out += [F.pad(ts[12], (0, 0, 0, pad)), F.pad(ts[13], (0, pad))]                 # W0 [W,32], b0 [W]
+    for h in range(5):
+        w1, b1, w2, b2 = ts[14 + 4 * h:18 + 4 * h]
+        out += [F.pad(w1, (0, pad, 0, pad)), F.pad(b1, (0, pad)), F.pad(w2, (0, pad)), b2]
+    return out
 
 
 # Data-parallel hook: the gradient of the SH coefficients leaves the deformation field unchanged (shs_final =
@@ -245,12 +269,13 @@ class _DeformFunction(torch.autograd.Function):
         # fp32-MFMA mode keeps hidden [N,128]; split mode keeps relu(hidden) twice as operand pieces (768 B/point
         # each: lane = point for the dW2 recompute, points-as-K for the dW1 products) and the ReLU bit masks
         # (96 B/point); relu(h1) is recomputed
-        hidden = torch.empty(N, net.W, device=dev, dtype=torch.float32) if (need_grad and not split_saves) else None
+        hidden = torch.empty(N, KERNEL_WIDTH, device=dev, dtype=torch.float32) if (need_grad and not split_saves) else None
         act = torch.empty((N + 31) // 32 * 32, 192, device=dev, dtype=torch.float32) if split_saves else None
         yhid = torch.empty((N + 15) // 16 * 16 + 16, 192, device=dev, dtype=torch.float32) if split_saves else None
         mask = torch.empty(N, 12, device=dev, dtype=torch.int64) if split_saves else None
         yfeat = torch.empty((N + 15) // 16 * 16 + 16, 48, device=dev, dtype=torch.float32) if split_saves else None
-        P = _fill_params(net)
+        kparams = [p.detach() if p.is_contiguous() else p.detach().contiguous() for p in params]
+        P = _fill_params(net, tensors=kparams)
         ws_bytes = lib.fdgs_deform_fwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
         a = _lib.DeformFwdArgs(N, P, ptr(xyz_c), ptr(sc_c), ptr(ro_c), ptr(op_c), ptr(sh_c), ptr(time_c), time_scalar,
@@ -259,16 +284,17 @@ class _DeformFunction(torch.autograd.Function):
         _lib.call("fdgs_deform_fwd", a)
         ctx.net = net
         ctx.time_scalar = time_scalar
-        ctx.param_versions = [p._version for p in params]
+        ctx.param_versions = [p._version for p in _trainable(net)]
         ctx.param_generation = adam.GENERATION[0]       # FusedAdam writes through raw pointers: no version bump
         ctx.matmul = MATMUL
-        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act, mask, yhid, yfeat)
+        ctx.save_for_backward(xyz_c, time_c, hidden, ws, act, mask, yhid, yfeat, *kparams)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_xyz, g_sc, g_ro, g_op, g_sh):
         net = ctx.net
-        xyz_c, time_c, hidden, fwd_ws, act, mask, yhid, yfeat = ctx.saved_tensors
+        xyz_c, time_c, hidden, fwd_ws, act, mask, yhid, yfeat = ctx.saved_tensors[:8]
+        kparams = list(ctx.saved_tensors[8:])            # the tensors the forward ran on (padded for a narrow network)
         N = xyz_c.shape[0]
         dev = xyz_c.device
         def c(t, shape):
@@ -278,19 +304,22 @@ class _DeformFunction(torch.autograd.Function):
         g_xyz = c(g_xyz, (N, 3)); g_sc = c(g_sc, (N, 3)); g_ro = c(g_ro, (N, 4))
         g_op = c(g_op, (N, 1)); g_sh = c(g_sh, (N, 16, 3))
         params = _trainable(net)
-        # one zero-filled flat buffer, viewed per parameter (the library accumulates into it)
-        order, sizes, shapes = net._fdgs_grad_order, net._fdgs_grad_sizes, net._fdgs_grad_shapes
+        # one zero-filled flat buffer, viewed per parameter (the library accumulates into it); every tensor whose size
+        # is a multiple of 16 floats first, so that each starts on a 64-byte boundary
+        order = sorted(range(len(kparams)), key=lambda i: (kparams[i].numel() % 16 != 0, i))
+        sizes = [kparams[i].numel() for i in order]
         flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
-        grads = [None] * len(params)
-        for i, piece, shape in zip(order, flat.split_with_sizes(sizes), shapes):
-            grads[i] = piece.view(shape)
-        P = _fill_params(net)
+        grads = [None] * len(kparams)
+        for i, piece in zip(order, flat.split_with_sizes(sizes)):
+            grads[i] = piece.view(kparams[i].shape)
+        P = _fill_params(net, tensors=kparams)
         P.matmul = ctx.matmul
         G = _fill_params(net, grads)
         d_xyz = torch.empty_like(xyz_c)
         # the forward's channel-last plane copies are still valid if no parameter was written since
+        # (the twelve planes are always the module's own tensors, also for a padded network)
         unchanged = (ctx.param_generation == adam.GENERATION[0]
-                     and all(p._version == v for p, v in zip(params, ctx.param_versions)))
+                     and all(p._version == v for p, v in zip(params[:12], ctx.param_versions[:12])))
         planes_cl = ptr(fwd_ws) if unchanged else None
         ws_bytes = lib.fdgs_deform_bwd_workspace_bytes(C.byref(P), N)
         ws = torch.empty(max(ws_bytes, 16), device=dev, dtype=torch.uint8)
@@ -323,12 +352,12 @@ class DeformationFields(nn.Module):
         self.multires = kwargs["multires"]
         self.empty_voxel = kwargs["empty_voxel"]
         self.static_mlp = kwargs["static_mlp"]
-        if (self.net_width != 128 or self.defor_depth > 1 or self.grid_pe != 0 or self.empty_voxel or
-                self.static_mlp or len(self.multires) != 2 or self.kplanes_config["output_coordinate_dim"] != 16 or
-                self.kplanes_config["grid_dimensions"] != 2 or self.kplanes_config["input_coordinate_dim"] != 4):
-            raise NotImplementedError("libfdgs implements the shipped DyNeRF deformation configuration "
-                                      "(configs/train/dynerf.yaml:85-111): width 128, defor_depth 0/1, two levels, "
-                                      "16 channels, no grid PE / static MLP / empty voxel")
+        if (not (1 <= self.net_width <= KERNEL_WIDTH) or self.defor_depth > 1 or self.grid_pe != 0 or self.empty_voxel
+                or self.static_mlp or len(self.multires) != 2 or self.kplanes_config["output_coordinate_dim"] != 16
+                or self.kplanes_config["grid_dimensions"] != 2 or self.kplanes_config["input_coordinate_dim"] != 4):
+            raise NotImplementedError("libfdgs implements the shipped deformation configurations "
+                                      "(configs/train/dynerf.yaml:85-111, dnerf.yaml:83-107): width up to 128, "
+                                      "defor_depth 0/1, two levels, 16 channels, no grid PE / static MLP / empty voxel")
         self.deformation_net = DeformationNet(self.net_width, self.grid_pe, self.bounds, self.kplanes_config,
                                               self.multires)
         self.register_buffer("time_poc", torch.FloatTensor([(2 ** i) for i in range(self.timebase_pe)]))
@@ -350,7 +379,7 @@ class DeformationFields(nn.Module):
     def forward_dynamic(self, point, scales=None, rotations=None, opacity=None, shs=None, time=None):
         net = self.deformation_net
         return _DeformFunction.apply(net, torch.is_grad_enabled(), point, scales, rotations, opacity, shs, time,
-                                     *_trainable(net))
+                                     *_kernel_parameters(net))
 
     def get_mlp_parameters(self):
         return self.deformation_net.get_mlp_parameters()

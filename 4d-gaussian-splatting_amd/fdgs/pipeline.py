@@ -64,7 +64,8 @@ class ViewPipeline:
         g = self.g
         return (g.scaling_activation is torch.exp and g.opacity_activation is torch.sigmoid
                 and g.rotation_activation is torch.nn.functional.normalize
-                and ("coarse" in stage or self.net is not None))
+                and ("coarse" in stage or (self.net is not None
+                                           and self.net.deformation_net.W == _deformation.KERNEL_WIDTH)))
 
     def ensure(self, N, W, H, dev, deform_numel=None):
         """Allocates (or re-allocates, when a size changed) the persistent buffers; run() does it by itself, a

@@ -13,8 +13,12 @@ CASES = {
     # name: (resolution[x,y,z,t], multires, n_points)
     "tiny": ([8, 6, 5, 10], [1, 2], 777),
     "dynerf": ([64, 64, 64, 150], [1, 2], 1536),   # configs/train/dynerf.yaml:95-101
+    "dnerf64": ([12, 9, 7, 25], [1, 2], 900),      # net_width 64 as configs/train/dnerf.yaml:83 (small planes)
+    "narrow40": ([8, 6, 5, 10], [1, 2], 333),      # a width that is no multiple of 32, defor_depth 1 (= 0: create_net
+                                                   # adds layers from depth 2 on, src/model/deformation.py:72-75)
 }
-WIDTH = 128
+WIDTHS = {"dnerf64": 64, "narrow40": 40}           # net_width of a case; 128 (configs/train/dynerf.yaml:85) otherwise
+DEPTHS = {"narrow40": 1}
 FEAT = 16
 HEAD_DIMS = {"pos": 3, "scales": 3, "rotations": 4, "opacity": 1, "shs": 48}
 AABB_MAX = [2.5, 2.0, 1.0]      # configs/train/dynerf.yaml:69-70
@@ -23,7 +27,7 @@ AABB_MIN = [-2.5, -2.0, -1.0]
 
 def net_kwargs(case):
     reso, multires, _ = CASES[case]
-    return dict(net_width=WIDTH, timebase_pe=4, defor_depth=0, posebase_pe=10,
+    return dict(net_width=WIDTHS.get(case, 128), timebase_pe=4, defor_depth=DEPTHS.get(case, 0), posebase_pe=10,
                 scale_rotation_pe=2, opacity_pe=2, grid_pe=0, no_grid=False, bounds=1.6,
                 kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4,
                                 "output_coordinate_dim": FEAT, "resolution": list(reso)},
@@ -33,6 +37,7 @@ def net_kwargs(case):
 def make_state(case):
     """state_dict with the reference's 39 keys, filled deterministically."""
     reso, multires, _ = CASES[case]
+    WIDTH = WIDTHS.get(case, 128)
     sd = {}
     sd["time_poc"] = torch.tensor([2.0 ** i for i in range(4)])
     sd["pos_poc"] = torch.tensor([2.0 ** i for i in range(10)])

@@ -1,7 +1,7 @@
 """Generate tests/golden/deform_<case>.npz from the reference's own modules.
 
 Run in the authoring container only (it needs /root/reference):
-    python tests/golden/make_deform_golden.py
+    python tests/golden/make_deform_golden.py [case ...]
 
 The reference modules are imported as they are; three third-party modules that
 its import chain names but this path never calls (tkinter, plyfile,
@@ -43,7 +43,10 @@ def import_reference():
 def main():
     deformation, _ = import_reference()
     torch.set_num_threads(8)
+    only = sys.argv[1:]                      # case names; none = all
     for case in dc.CASES:
+        if only and case not in only:
+            continue
         net = deformation.DeformationFields(dc.net_kwargs(case))
         sd = dc.make_state(case)
         ref_keys = list(net.state_dict().keys())

@@ -65,7 +65,7 @@ def check_regulation_against_golden(case, loss, grads):
             assert abs(float(g.double().sum()) - s) <= 1e-5 * sa
 
 
-@pytest.mark.parametrize("case", list(dc.CASES))
+@pytest.mark.parametrize("case", ["tiny", "dynerf"])      # the cases tests/golden/reg_*.npz hold
 def test_regulation_oracle_matches_reference_golden(case):
     """oracle compute_regulation against the values the reference's DeformationWrapper.compute_regulation
     produced (tests/golden/make_reg_golden.py)."""
