@@ -293,6 +293,35 @@ def cpu_baseline(args, g, net, cam, bg):
             "estimated_step_seconds": est}
 
 
+def blend_row_evaluations(p):
+    """How many (list entry, 16-pixel row) evaluations the blend backward made for the view whose buffers the
+    pipeline `p` still holds: every entry of a tile's list is evaluated on the 4 x 4-pixel rows (four per 8 x 8
+    quadrant) that the forward's verdict byte says its 1/255-alpha ellipse reaches, up to that row's last
+    contributor.  One such evaluation is one step of one DPP row in blend_bwd_kernel's inner loop."""
+    H, W = p.n_contrib.shape
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    nc = torch.zeros(gy * 16, gx * 16, dtype=torch.int32, device=p.n_contrib.device)
+    nc[:H, :W] = p.n_contrib
+    # y = (tile, quadrant, row, pixel) x = (tile, quadrant, row, pixel): the last contributor of every row
+    last = nc.view(gy, 2, 2, 4, gx, 2, 2, 4).amax(dim=(3, 7)).permute(0, 3, 1, 4, 2, 5).reshape(gy * gx, 4, 4)
+    ranges = p.ranges.long()
+    lens = ranges[:, 1] - ranges[:, 0]
+    R = int(lens.sum())
+    if R == 0:
+        return 0
+    tile = torch.repeat_interleave(torch.arange(gy * gx, device=lens.device), lens)
+    first = torch.repeat_interleave(ranges[:, 0], lens)
+    order = torch.argsort(first, stable=True)           # the lists lie in tile order; keep it explicit
+    tile, first = tile[order], first[order]
+    pos = (torch.arange(R, device=lens.device) - first).to(torch.int32)       # position inside the tile's list
+    verdict = p.keys_a.view(torch.uint8)[:4 * R].view(R, 4).to(torch.int32)    # one byte per quadrant, bit = row
+    total = 0
+    for row in range(4):
+        reach = ((verdict >> row) & 1).bool()
+        total += int((reach & (pos[:, None] < last[tile, :, row])).sum())
+    return total
+
+
 def main():
     global torch, dist
     argv = sys.argv[1:]
@@ -329,6 +358,7 @@ def main():
         if share_gpu:
             dist.init_process_group(backend="gloo")
         else:
+            os.environ.setdefault("NCCL_ALGO", "Ring")      # see fdgs/dp.py: no packed fp32 in RCCL's ring sum kernels
             dist.init_process_group(backend="nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
@@ -385,6 +415,13 @@ def main():
     sync()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     prof, _lib.PROFILE = _lib.PROFILE, None
+    row_evals = None
+    if rank == 0 and step.use_pipeline and step.pipeline.capacity > 0:
+        try:
+            torch.cuda.synchronize()
+            row_evals = blend_row_evaluations(step.pipeline)        # of the last timed view
+        except Exception:                                           # a diagnostic figure: the line must still come out
+            row_evals = None
     if _lib.PROFILE_ONLY is not None:      # kernel_ms of every entry point: the same steps continued, not timed as a whole
         _lib.PROFILE, _lib.PROFILE_ONLY = {}, None
         for i in range(min(args.steps, 40)):
@@ -528,10 +565,23 @@ def main():
                 if sq and dur > 0:
                     peak = sq["valu_issue_peak_ginst_per_s"]
                     rate = sq["valu_insts_per_launch"] / dur / 1e9
+                    # peak: the issue rate a microbenchmark of independent v_fma_f32 reaches on this part
+                    # (tools/microbench/valu_rate.hip); spec_peak: the 157.3 TFLOP/s fp32 vector figure = one wave64
+                    # FMA per SIMD every 2 cycles at 2.4 GHz on 1024 SIMDs
+                    spec = 157.3e12 / 2.0 / 64.0 / 1e9
                     valu_roofline = {"kernel": "blend_bwd_kernel", "bound": "valu-issue", "achieved": rate,
                                      "peak": peak, "unit": "G wave-instructions/s", "frac": rate / peak,
+                                     "spec_peak": spec, "frac_of_spec_peak": rate / spec,
                                      "valu_insts_per_launch": sq["valu_insts_per_launch"],
                                      "counters_from": os.path.basename(f)}
+                    if row_evals:
+                        # the last timed view's (entry, 16-pixel row) evaluations, scaled to the mean list length of
+                        # the timed views.  A wave instruction serves four rows at once, so a loop whose four rows
+                        # were always busy would spend a quarter of its instructions per step on each evaluation;
+                        # the figure includes the idle rows' share and everything outside the inner loop.
+                        evals = row_evals * (R / max(rendered[-1], 1))
+                        valu_roofline["entry_row_evaluations_per_launch"] = evals
+                        valu_roofline["wave_insts_per_entry_row_evaluation"] = sq["valu_insts_per_launch"] / evals
         mlp_s = (avg_ms("fdgs_deform_fwd") + avg_ms("fdgs_deform_bwd")) * 1e-3 or 1.0
         mlp_flop = 3 * 187136.0 * args.gaussians          # fp32 semantics, forward + backward, per view
         out = {
