@@ -101,32 +101,49 @@ def main(flag_dir, cycles):
     step, cams = build(dev)
     p = step.pipeline
     names = ("out0", "out1", "out2", "out3", "out4", "fws", "yfeat", "act", "mask", "yhid", "geom", "radii", "touched",
-             "offsets", "ranges", "color", "finalT", "ncontrib", "gradimage")
+             "offsets", "ranges", "color", "finalT", "ncontrib", "gradimage", "arena")
+    # "arena" = every gradient of the view (deformation field, positions, view-space, scaling, rotation, opacity, SH).
+    # The backward kernels accumulate with atomics, so it is compared to a tolerance: 2e-5 of the largest magnitude of
+    # each region (run-to-run noise of the atomics' order is about 2e-7), not bit by bit.
+    TOL = {"arena": 2e-5}
 
     def buffers():
         return (p.d_out[0], p.d_out[1], p.d_out[2], p.d_out[3], p.d_out[4], p._deform_ws[0], p.yfeat, p.act, p.mask,
                 p.yhid, p.geom, p.radii, p.tiles_touched, p.point_offsets, p.ranges, p.color, p.final_T, p.n_contrib,
-                p.grad_image)
+                p.grad_image, p.arenas[state["set"]])
 
     def as_int(t):
         return t.view(torch.int32) if t.dtype in (torch.float32,) else t
 
-    state = {"view": 0, "mode": "ref", "ref": [], "flags": [], "kept": []}
+    def differs(name, b, r):
+        if name not in TOL:
+            return (as_int(b) != as_int(r)).any()
+        m = p.arena_marks
+        bad = torch.zeros((), dtype=torch.bool, device=b.device)
+        marks = sorted(m.values())
+        for lo, hi in zip(marks, marks[1:]):
+            if hi > lo:
+                scale = r[lo:hi].abs().max()
+                bad = bad | ((b[lo:hi] - r[lo:hi]).abs().max() > TOL[name] * scale + 1e-30)
+        return bad
+
+    state = {"view": 0, "mode": "ref", "ref": [], "flags": [], "kept": [], "set": 0}
     inner = p.run
 
     def run(cam, *a, **k):
         out = inner(cam, *a, **k)
         v = state["view"]
         state["view"] += 1
+        state["set"] = k.get("grad_set", 0)
         bufs = buffers()
         if state["mode"] == "ref":
             state["ref"].append([b.clone() for b in bufs])
         elif state["mode"] == "ref2":
             ref = state["ref"][v]
-            state["flags"].append(torch.stack([(as_int(b) != as_int(r)).any() for b, r in zip(bufs, ref)]))
+            state["flags"].append(torch.stack([differs(nm, b, r) for nm, b, r in zip(names, bufs, ref)]))
         else:
             ref = state["ref"][v]
-            flag = torch.stack([(as_int(b) != as_int(r)).any() for b, r in zip(bufs, ref)])
+            flag = torch.stack([differs(nm, b, r) for nm, b, r in zip(names, bufs, ref)])
             state["flags"].append(flag)
             # keep the buffers of this view until the cycle's flags have been read (cheap at this size)
             state["kept"].append([b.clone() for b in bufs])
@@ -180,6 +197,8 @@ def main(flag_dir, cycles):
     print("fws bytes", fws_bytes, "feat_split at byte", feat_off, "(mod 256 =", feat_off % 256, ") base mod 256 =",
           p._deform_ws[0].data_ptr() % 256, flush=True)
 
+    order = sorted((off, nm) for nm, off in p.arena_marks.items())
+    state["regions"] = [(lo, hi, nm) for (lo, nm), (hi, _) in zip(order, order[1:])]
     open(os.path.join(flag_dir, "ready"), "w").close()
     state["mode"] = "probe"
     t0 = time.time()
@@ -229,6 +248,13 @@ def report(cyc, v, flag, state, names, n, feat_off, feat_bytes, times):
         if not bool(flag[i]):
             continue
         g, r = got[i], ref[i]
+        if name == "arena":
+            line = "   arena (largest deviation / largest magnitude per region):"
+            for lo, hi, nm in state["regions"]:
+                if hi > lo:
+                    line += f" {nm} {float((g[lo:hi] - r[lo:hi]).abs().max() / (r[lo:hi].abs().max() + 1e-30)):.1e}"
+            print(line, flush=True)
+            continue
         if name == "fws":
             gb, rb = g.view(torch.uint8), r.view(torch.uint8)
             idx = (gb != rb).nonzero().flatten()
