@@ -237,7 +237,7 @@ def test_library_has_no_packed_fp32_arithmetic():
 
 
 def test_integration_document_matches_header_and_abi():
-    """INTEGRATION.md's ctypes example is the output of tools/gen_integration_stub.py for the current header (a reader
+    """The integration guide's ctypes example is the output of tools/gen_integration_stub.py for the current header (a reader
     who copies it passes a structure of the right length), the structure it defines has the binding's own layout,
     and every ABI number the document quotes is the library's."""
     import ctypes
@@ -245,7 +245,7 @@ def test_integration_document_matches_header_and_abi():
     import sys
     from fdgs import _lib
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_integration_stub.py"), "--check"])
-    assert r.returncode == 0, "INTEGRATION.md is stale: run python tools/gen_integration_stub.py"
+    assert r.returncode == 0, "the integration guide is stale: run python tools/gen_integration_stub.py"
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     quoted = [int(v) for v in re.findall(r"fdgs_abi_version\(\)`? (?:is|==) (\d+)", doc)]
     assert quoted and all(v == _lib.lib.fdgs_abi_version() for v in quoted), quoted

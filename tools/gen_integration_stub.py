@@ -1,8 +1,8 @@
-"""Writes the ctypes example of INTEGRATION.md section 5 from include/fdgs.h, so that the document cannot drift from
+"""Writes the ctypes example of the integration guide from include/fdgs.h, so that the document cannot drift from
 the header: the fields of fdgs_blend_fwd_args in declaration order (int32_t -> c_int32, float -> c_float, pointers ->
 c_void_p) and the ABI number from csrc/api.hip.  The block between the two marker comments is replaced.
 
-    python tools/gen_integration_stub.py            rewrites INTEGRATION.md in place
+    python tools/gen_integration_stub.py            rewrites the guide in place
     python tools/gen_integration_stub.py --check    exits 1 if the file would change
 """
 import os
