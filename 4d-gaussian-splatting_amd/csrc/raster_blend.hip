@@ -1,15 +1,16 @@
 // Rasterizer stage 6 (front-to-back alpha blending) and stage 7 (its backward).
 //
 // gfx950 mapping: one 256-thread workgroup per 16x16 tile; each of its four wavefronts owns one 8x8 pixel quadrant
-// and walks the tile's depth-sorted list on its own, with no workgroup barrier.  Inside the wave, each of the four
+// and walks the tile's depth-sorted list (the forward on its own, with no workgroup barrier; the backward in step
+// with the tile's other waves, one barrier per batch, see blend_bwd_kernel).  Inside the wave, each of the four
 // 16-lane DPP rows owns one 4x4 pixel block and walks ITS OWN list of survivors: a batch of 64 list entries is loaded
 // one per lane, every lane tests its entry's 1/255-alpha box against the four blocks, four 64-bit ballots collect the
 // survivors per block, and in every step each row takes the next survivor of its own block.  Splats here cover a
 // third of an 8x8 quadrant on average: with one survivor per wave and step two thirds of the lanes computed nothing.
 // A survivor's record reaches its row through a wave-private LDS copy of the batch (same-address reads within a
 // row; an LDS read is not a vector instruction, and both kernels are bound by vector-instruction issue).  A row
-// whose list is exhausted reads a null record (opacity 0: never contributes).  No workgroup barrier: a wave's LDS
-// instructions execute in program order.
+// whose list is exhausted reads a null record (opacity 0: never contributes).  The wave-private LDS areas need no
+// barrier: a wave's LDS instructions execute in program order.
 //
 // The conic is staged pre-scaled, a2 = -log2(e) A, b1 = -log2(e) B, c2 = -log2(e) C, so that
 // exp(power) = exp2(dx (a2 dx / 2 + b1 dy) + c2 dy^2 / 2) needs no further constant, and the backward accumulates
@@ -250,6 +251,15 @@ __device__ __forceinline__ void butterfly_top(float v0, float v1, float v2, floa
         : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7));
 }
 
+// The four waves of a tile walk the same batches (from the tile's last contributor down) and add their rows' sums
+// into ONE accumulator per batch entry; after a workgroup barrier each wave hands a quarter of the batch's entries to
+// memory - one request per (tile, entry, component) instead of one per (quadrant, entry, component): the
+// memory-side atomic units are paced by requests.  Two accumulators alternate, so one barrier per batch orders
+// everything: a wave adds into accumulator b & 1 only after the barrier of batch b - 1, which every wave reaches
+// after it has flushed and cleared its quarter of batch b - 2.  (Measured against four private accumulators
+// flushed per wave with no barrier: 0.221 -> 0.205 ms in the training step, bytes written per launch 122 -> 61 MiB;
+// the accumulators take 9 KB instead of 18 and the kernel 70 registers instead of 87, so seven workgroups share a
+// compute unit instead of five, which more than pays for the waves waiting at the barrier.)
 __global__ void __launch_bounds__(256)
 blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     const int tile = a.tile_order ? (int)a.tile_order[blockIdx.x] : (int)blockIdx.x;
@@ -265,7 +275,7 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     const float bx = (float)qx0, by = (float)qy0;
 
     const uint32_t r_begin = a.ranges[2 * tile], r_end = a.ranges[2 * tile + 1];
-    if (r_begin >= r_end) return;
+    if (r_begin >= r_end) return;                   // the whole workgroup leaves: no barrier is missed
     const float4* __restrict__ geom4 = reinterpret_cast<const float4*>(a.geom);
 
     float T_final = 1.0f, dLr = 0.f, dLg = 0.f, dLb = 0.f;
@@ -310,13 +320,17 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
     // slower on this part) and handed to memory once per batch, nine consecutive floats per entry: the memory-side
     // atomic units are paced by requests, not bytes, and one request per row and step - four records per
     // instruction - made them the bottleneck.
-    __shared__ double sums[4][64 * 9];
-    double* __restrict__ mysum = sums[wave];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) mysum[64 * k + lane] = 0.0;
+    __shared__ double sums[2][64 * 9];
+    __shared__ int s_last[4];
+    for (int q = (int)threadIdx.x; q < 2 * 64 * 9; q += 256) sums[0][q] = 0.0;
+    if (lane == 0) s_last[wave] = wave_last;
+    __syncthreads();
+    const int tile_last = max(max(s_last[0], s_last[1]), max(s_last[2], s_last[3]));
     char* __restrict__ dbase = reinterpret_cast<char*>(a.dL_dgeom);
 
-    for (int hi = wave_last; hi > 0; hi -= 64) {
+    int batch = 0;
+    for (int hi = tile_last; hi > 0; hi -= 64, ++batch) {      // the same trips for the four waves: barriers inside
+        double* __restrict__ mysum = sums[batch & 1];
         const int pos = hi - 1 - lane;        // 0-based position in the tile list, back to front
         const bool valid = pos >= 0;
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
@@ -399,20 +413,22 @@ blend_bwd_kernel(fdgs_blend_bwd_args a, int tiles_x) {
             if (stores && out != 0.0f)          // an exhausted or untouched row has nothing to add
                 atomicAdd(&mysum[j * 9 + comp], (double)out);
         }
-        if (steps == 0) continue;
         // hand the batch's sums to memory and leave the LDS slots zero: slot q = 9 entry + component
+        __syncthreads();                      // every wave's sums of this batch are in
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int q = 64 * k + lane;
-            const int e = (q * 7282) >> 16;                          // q / 9 for q < 576
-            const unsigned long long bits =
-                atomicExch(reinterpret_cast<unsigned long long*>(&mysum[q]), 0ull);
-            const float f = (float)__longlong_as_double((long long)bits);
-            if (f != 0.0f) {
-                const float4 rec = my[e * 3 + 2];
-                const unsigned long long goff = (unsigned long long)__float_as_uint(rec.y) |
-                                                ((unsigned long long)__float_as_uint(rec.z) << 32);
-                atomicAdd(reinterpret_cast<float*>(goff + 4 * (q - 9 * e)), f);
+        for (int k = 0; k < 3; ++k) {         // this wave's quarter: entries 16 wave .. 16 wave + 15
+            const int q = 144 * wave + 64 * k + lane;
+            if (64 * k + lane < 144) {
+                const int e = (q * 7282) >> 16;                      // q / 9 for q < 576
+                const unsigned long long bits =
+                    atomicExch(reinterpret_cast<unsigned long long*>(&mysum[q]), 0ull);
+                const float f = (float)__longlong_as_double((long long)bits);
+                if (f != 0.0f) {
+                    const float4 rec = my[e * 3 + 2];                // every wave staged the same batch
+                    const unsigned long long goff = (unsigned long long)__float_as_uint(rec.y) |
+                                                    ((unsigned long long)__float_as_uint(rec.z) << 32);
+                    atomicAdd(reinterpret_cast<float*>(goff + 4 * (q - 9 * e)), f);
+                }
             }
         }
     }

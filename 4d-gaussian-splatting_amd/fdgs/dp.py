@@ -65,14 +65,22 @@ def all_reduce_(t, op, group=None):
         dist.all_reduce(t, op=op, group=group)
 
 
+class _Completed:
+    """Handle of a reduction that has already taken place."""
+
+    def wait(self):
+        return True
+
+
 def all_reduce_async(t, op=None, group=None):
     """Starts an in-place SUM all-reduce of `t` on the communication stream and returns a handle; its wait()
     orders the current stream after the collective without blocking the host, so kernels enqueued between
-    the two calls run beside it.  Returns None when the reduction has already completed (gloo staging)."""
+    the two calls run beside it.  Always returns a handle: with gloo staging of a device tensor the reduction is
+    complete on return and the handle's wait() does nothing (callers take "no handle" to mean "no collective")."""
     op = dist.ReduceOp.SUM if op is None else op
     if t.is_cuda and dist.get_backend(group) == "gloo":
         all_reduce_(t, op, group)
-        return None
+        return _Completed()
     return dist.all_reduce(t, op=op, group=group, async_op=True)
 
 
