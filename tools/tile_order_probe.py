@@ -1,6 +1,11 @@
 """Times the two blend kernels at 300k Gaussians / 1352x1014 under different tile orders (which tile workgroup i
-takes): the library's own (longest lists first), and orders that keep spatial neighbourhoods on one XCD (workgroup i
-runs on XCD i mod 8) while still starting long lists first within each XCD.
+takes): the library's own (longest lists first), image order, and orders that keep spatial neighbourhoods on one XCD
+(workgroup i runs on XCD i mod 8: positions r, r + 8, ... hold the tiles of the super-tiles with
+(sx + 3 sy) mod 8 == r) with different orders inside an XCD's share.
+
+Result on MI355X: with settled clocks the XCD-aware orders are no faster than the library's; a share in random or
+image order is slower (long lists must start first).  Every variant runs 100 warm-up launches and the first ones are
+measured again at the end: without that the variants measured first look 15-20 % slower than they are.
 
     python tools/tile_order_probe.py [super-tile edge, in tiles: 0 = contiguous bands] ...
 """
