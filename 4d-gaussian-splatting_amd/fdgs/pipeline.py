@@ -58,6 +58,10 @@ class ViewPipeline:
         self.capacity = 0
         self._one = None
         self.deform_numel = 0                    # floats reserved in the gradient arena for the deformation field
+        # FDGS_ASIDE=0: the view-independent work runs on the view's own stream while the host waits for the
+        # tile-list length, as it does in the coarse stage
+        self.aside = os.environ.get("FDGS_ASIDE", "1") != "0"
+        self._aside = None                       # (stream, event before the view, event after the work)
 
     # ------------------------------------------------------------------------------------------------------
     def usable(self, stage):
@@ -205,6 +209,7 @@ class ViewPipeline:
         pm = cam.full_proj_transform
         cp = cam.camera_center
         acts = _lib.ACT_SCALE_EXP | _lib.ACT_ROTATION_NORMALIZE | _lib.ACT_OPACITY_SIGMOID
+        side_term = side_pending = None
 
         if fine:
             net = self.net.deformation_net
@@ -219,7 +224,25 @@ class ViewPipeline:
                                    None if split else ptr(self.hidden), ptr(self.act) if split else None,
                                    ptr(self.mask) if split else None, ptr(self.yhid) if split else None,
                                    ptr(self.yfeat) if split else None, ptr(fws), fws_bytes, ptr(f_rest))
+            # work that depends on no view (the caller's regulariser and gradient clears) goes to a second stream,
+            # ordered after everything enqueued before this view and submitted behind the deformation forward: its
+            # workgroups fill the compute units that kernel's last, partly empty round leaves idle (300,000 points
+            # are 4.58 rounds of one-wave-per-SIMD tiles) instead of standing between the preprocess kernel and the
+            # tile lists
+            if while_waiting is not None and self.aside:
+                cur = torch.cuda.current_stream()
+                if self._aside is None or self._aside[0].device != cur.device:
+                    with torch.cuda.device(cur.device):
+                        self._aside = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+                side, before, after = self._aside
+                before.record(cur)
             _lib.call("fdgs_deform_fwd", a)
+            if while_waiting is not None and self.aside:
+                side.wait_event(before)
+                with torch.cuda.stream(side):
+                    side_term = while_waiting()
+                    after.record(side)
+                while_waiting, side_pending = None, after
             m3, scales, rots, opac, shs = o[0], o[1], o[2], o[3].reshape(-1), o[4]
         else:
             m3, scales, rots, opac, shs = xyz, sc, ro, op.reshape(-1), self.shs_in
@@ -234,7 +257,7 @@ class ViewPipeline:
         self.r_host.copy_(self.scan_ws[:3], non_blocking=True)     # depth range (two words) and R
         ready = torch.cuda.Event()
         ready.record()
-        loss_term = while_waiting() if while_waiting is not None else None
+        loss_term = while_waiting() if while_waiting is not None else side_term
 
         def binsort_args():
             return _lib.BinSortArgs(N, W, H, 0, ptr(self.geom), ptr(self.point_offsets), ptr(self.keys_a),
@@ -286,6 +309,8 @@ class ViewPipeline:
         bs.phase = _lib.BINSORT_FINISH if counted else _lib.BINSORT_ALL
         if R == 0:
             bf.point_list = bb.point_list = None
+        if side_pending is not None:
+            torch.cuda.current_stream().wait_event(side_pending)
         _lib.call("fdgs_raster_bin_sort", bs)
         _lib.call("fdgs_raster_blend_fwd", bf)
         _lib.call("fdgs_l1_loss_fwd", l1)
