@@ -614,6 +614,9 @@ def main():
             "render_fps_with_d2h": fps_d2h,
             "render_fps_with_d2h_host_conversion": fps_d2h_host,
             "kernel_ms": per_call,
+            "kernel_ms_note": "HIP events around each C-ABI call on the stream it is enqueued on; fdgs_plane_regulation "
+                              "runs on a second stream beside fdgs_deform_fwd (FDGS_ASIDE), so its figure is time in "
+                              "flight while sharing the chip (0.026 ms alone), not time added to the step",
             # deformation MLP, forward + backward: 3 x 187,136 flop per point in fp32 semantics.  The split mode
             # issues six bf16 MFMA terms per product: issued bf16 flop = 6 x that, against the dense bf16 peak;
             # the fp32-equivalent figure against the fp32 matrix-core peak is kept beside it.  The two calls
