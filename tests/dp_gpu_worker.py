@@ -28,7 +28,7 @@ def main(out_dir):
     if grouped:
         dist.init_process_group(backend=backend, **({"device_id": dev} if backend == "nccl" else {}))
     torch.manual_seed(ss.SEED + rank)            # different RNG state per rank: TrainStep must equalise the replicas
-    n, w, h = 6000, 160, 120
+    n, w, h = (int(v) for v in os.environ.get("FDGS_TEST_SCENE", "6000,160,120").split(","))
     g = ss.GaussianParams(n, device=dev, scale_mult=3.0)
     net = ss.perturb_deformation_(DeformationFields(ss.DYNERF_NET_KWARGS)).to(dev)
     net.deformation_net.set_aabb(list(ss.SCENE_MAX), list(ss.SCENE_MIN))

@@ -28,12 +28,14 @@ def _same_to_rounding(got, ref, name):
         f"{name}: max {float(diff.max()):.3e} of {scale:.3e}, {int((diff > 2e-5 * scale + 1e-12).sum())} elements beyond"
 
 
-@pytest.mark.parametrize("views", [2, 4])
-def test_two_ranks_match_one_rank(tmp_path, views):
+@pytest.mark.parametrize("views,scene", [(2, "6000,160,120"), (4, "6000,160,120"), (2, "100000,640,480")])
+def test_two_ranks_match_one_rank(tmp_path, views, scene):
     """views = 2: one view per rank (its SH gradient travels as a copy while the deformation backward runs);
-    views = 4: two per rank (the SH gradient travels after the rank's last view, summed in place)."""
+    views = 4: two per rank (the SH gradient travels after the rank's last view, summed in place).
+    scene: Gaussians, image width, image height (the larger one keeps the two processes on the GPU together for
+    long enough that each rank's kernels really run beside the other's)."""
     worker = os.path.join(HERE, "dp_gpu_worker.py")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FDGS_TEST_VIEWS=str(views))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", FDGS_TEST_VIEWS=str(views), FDGS_TEST_SCENE=scene)
     two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29541", worker, str(tmp_path)]
     r = subprocess.run(two, env=env, capture_output=True, text=True, timeout=280)
